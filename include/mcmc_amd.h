@@ -1,0 +1,156 @@
+/*
+ * mcmc_amd.h -- C ABI of the MI355X (gfx950) batched proposal-evaluation path
+ * of a-price/MCMC.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * This is the drop-in boundary for the PROBLEM concept of MCMC<PROBLEM>
+ * (reference include/MCMC.h:19-95; include/Problem.h:20-29): everything the
+ * reference computes between OverSegmentation handing over a Graph and
+ * Statistics being read back.  Each entry point cites the reference interface
+ * it replaces.  Status: 0 = ok, negative = error; mcmc_last_error() gives the
+ * text.  The reference reports the same conditions by throwing Exception_
+ * (include/MyMath.h:36-44).
+ *
+ * Threading: one context per (host thread, GPU); a context is not shared
+ * between threads (the reference is single-threaded and not re-entrant).
+ * All host buffers are owned by the caller.  Calls are asynchronous on the
+ * context's stream unless they return data to the host.
+ */
+#ifndef MCMC_AMD_H
+#define MCMC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMC_OK 0
+#define MCMC_E_BADARG (-1)       /* null pointer, size out of range, bad frame index */
+#define MCMC_E_DEVICE (-2)       /* HIP runtime error (text in mcmc_last_error) */
+#define MCMC_E_STATE (-3)        /* call out of order (e.g. chains before moments) */
+#define MCMC_E_NAN_RATIO (-4)    /* "Target/Proposal ratio is nan!" Problem.cpp:216-217, :443 */
+#define MCMC_E_INF_ENERGY (-5)   /* "log probability is inf" Graph.cpp:137 */
+#define MCMC_E_TOO_LARGE (-6)    /* superpixel count beyond what the chain kernel's LDS state holds */
+#define MCMC_E_NOSUPERPIXELS (-7)/* frame has no superpixel that passes the A1 filter */
+
+#define MCMC_NOLABEL 0xFFFFu     /* pixel / superpixel that belongs to no superpixel / segment */
+#define MCMC_MOMENT_STRIDE 10    /* N Su Sv Suu Suv Svv Sb Sub Svb Sbb (int64) */
+#define MCMC_FIT_STRIDE 12       /* Suu Suv Svv Su Sv N | Sub Svb Sb | theta_a theta_b theta_c (f64, centred) */
+
+typedef struct mcmc_ctx mcmc_ctx;
+
+/* Compile-time constants of the reference made run-time parameters
+ * (include/MyMath.h:28-32; src/libraries/Segmentation.cpp:16). */
+typedef struct mcmc_params {
+    int32_t width;               /* kWidth  = 640 */
+    int32_t height;              /* kHeight = 480 */
+    double disparity_variance;   /* kDisparityVariance = 7 */
+    double new_segment_prob;     /* newSegmentProb = 0.8 */
+    int32_t marginal_bins;       /* Lmax of the label-marginal histogram (build's choice, 64) */
+    int32_t visit_capacity;      /* distinct states counted per chain before overflow (256) */
+} mcmc_params;
+
+void mcmc_default_params(mcmc_params *p);
+
+/* ---- context ----------------------------------------------------------- */
+int mcmc_ctx_create(int device, const mcmc_params *params, mcmc_ctx **out);
+int mcmc_ctx_destroy(mcmc_ctx *ctx);
+const char *mcmc_last_error(const mcmc_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int mcmc_ctx_set_stream(mcmc_ctx *ctx, void *hip_stream);
+int mcmc_ctx_synchronize(mcmc_ctx *ctx);
+const char *mcmc_version(void);
+
+/* ---- frames: replaces what OverSegmentation::createSuperPixels leaves in
+ * Graph::superPixels_ (A_, b_, neighbors_, plane_) -- reference
+ * src/libraries/OverSegmentation.cpp:89-233, include/MyMath.h:177-183. ------ */
+
+/* Reserve device storage for n_frames frames of width x height pixels with at
+ * most s_max superpixels and e2_max directed adjacency entries each. */
+int mcmc_frames_alloc(mcmc_ctx *ctx, int n_frames, int s_max, int e2_max);
+
+/* Disparity plane (int16, the reference's .at<short>, OverSegmentation.cpp:148)
+ * and superpixel id per pixel (uint16; MCMC_NOLABEL = dropped pixel), host memory. */
+int mcmc_frame_upload(mcmc_ctx *ctx, int frame, const int16_t *disp, const uint16_t *label,
+                      int n_superpixels);
+/* Same, from device memory already resident in HBM (device-to-device copy). */
+int mcmc_frame_upload_device(mcmc_ctx *ctx, int frame, const void *d_disp, const void *d_label,
+                             int n_superpixels);
+/* Adjacency in CSR form, neighbours ascending by id: SuperPixel::neighbors_
+ * keys (include/MyMath.h:181; filled at OverSegmentation.cpp:186-190). */
+int mcmc_frame_set_graph(mcmc_ctx *ctx, int frame, const uint32_t *row_ptr, const uint32_t *col,
+                         uint32_t e2);
+
+/* K1 sp_moments + K1b local fit for frames [first, first+count):
+ * `new Plane(A, b)` -> solve() (OverSegmentation.cpp:219; MyMath.h:120-166)
+ * and the drop filter (OverSegmentation.cpp:198-222, 422-455). */
+int mcmc_frames_moments(mcmc_ctx *ctx, int first, int count);
+/* K2: Problem::computeEdgeProbs (src/libraries/Problem.cpp:76-114, 420-445). */
+int mcmc_frames_edge_probs(mcmc_ctx *ctx, int first, int count);
+
+int mcmc_frame_get_moments(mcmc_ctx *ctx, int frame, int64_t *out /* S*10 */);
+int mcmc_frame_get_local_fit(mcmc_ctx *ctx, int frame, double *fit /* S*12 */, uint8_t *valid /* S */,
+                             double *local_err /* S, Plane::error_, may be NULL */);
+int mcmc_frame_get_edge_probs(mcmc_ctx *ctx, int frame, double *q /* e2; -1 = edge to a dropped superpixel */);
+
+/* Segment(superPixels) constructor: computeHash + computeProbability
+ * (include/Graph.h:33-40; Graph.cpp:69-138).  theta3 is (a, b, c) of
+ * disparity = a*(u - W/2) + b*(v - H/2) + c. */
+int mcmc_segment_probability(mcmc_ctx *ctx, int frame, const uint32_t *members, int n_members,
+                             double *probL, double *theta3, double *err);
+
+/* ---- chains: Problem::initializeState + MCMC<Problem>::run with
+ * FastMetropolisHastings::iterate (Problem.cpp:447-473, 116-224; MCMC.h:43-89,
+ * 207-238; Segmentation.cpp:10-237; Statistics.h:33-70). -------------------- */
+
+/* n_chains independent chains; chain k samples frame k / chains_per_frame and
+ * draws from Philox4x32-10 keyed (seed, chain_offset + k), so a run sharded
+ * over several GPUs by chain_offset reproduces the single-GPU chains exactly. */
+int mcmc_chains_init(mcmc_ctx *ctx, int n_chains, int chains_per_frame, uint32_t seed,
+                     uint32_t chain_offset);
+/* burn_in steps without statistics then iters steps with Statistics::update
+ * after each (MCMC.h:55-82).  May be called repeatedly; steps continue. */
+int mcmc_chains_run(mcmc_ctx *ctx, uint64_t burn_in, uint64_t iters);
+/* Optional accept trace for parity tests: one byte per chain per step of the
+ * NEXT mcmc_chains_run, bit0 accept, bits1-2 case (0 own segment, 1 split,
+ * 2 merge/exchange), 0xFF = chain frozen by an error.  capacity_steps bytes
+ * per chain are reserved on the device; 0 disables. */
+int mcmc_chains_set_trace(mcmc_ctx *ctx, uint64_t capacity_steps);
+int mcmc_chains_get_trace(mcmc_ctx *ctx, uint8_t *out /* n_chains*steps of last run */);
+
+/* which: 0 current state, 1 best-energy state, 2 most-visited state
+ * (printResults uses the most visited, src/exe/can05_sampler.cpp:36).
+ * canonical != 0: first-appearance relabel of Segmentation::computeHash
+ * (Segmentation.cpp:197-233); else the smallest member id of each segment. */
+int mcmc_chains_get_labels(mcmc_ctx *ctx, int which, int canonical, uint16_t *out /* n_chains*s_max */);
+/* Any pointer may be NULL.  n_case: 3 per chain.  status: per-chain MCMC_E_*. */
+int mcmc_chains_get_scalars(mcmc_ctx *ctx, double *energy, double *best_energy, uint64_t *state_hash,
+                            uint64_t *trace_hash, uint64_t *n_accept, uint64_t *n_case,
+                            int32_t *status, uint64_t *top_count, uint64_t *top_hash,
+                            uint64_t *overflow);
+/* Statistics::entries_ per chain: visit_capacity (hash, count) slots, hash 0 count 0 = empty. */
+int mcmc_chains_get_visits(mcmc_ctx *ctx, uint64_t *hash, uint64_t *count);
+/* Label marginals of one frame summed over its chains: s_max*marginal_bins counts. */
+int mcmc_frame_get_marginals(mcmc_ctx *ctx, int frame, uint64_t *out);
+/* Segmentation::computeProbability (Segmentation.cpp:185-195) recomputed from the segment cache. */
+int mcmc_chains_recompute_energy(mcmc_ctx *ctx, double *out /* n_chains */);
+
+/* ---- measurement -------------------------------------------------------- */
+/* Device time of the most recent launch of each kernel, measured with HIP
+ * events on the context's stream: 0 sp_moments, 1 local_fit, 2 edge_prob,
+ * 3 chain_step.  Returns milliseconds, < 0 if never launched. */
+double mcmc_last_kernel_ms(mcmc_ctx *ctx, int kernel);
+int mcmc_set_timing(mcmc_ctx *ctx, int enable);
+
+/* Device self-test of the deterministic math shared by every kernel: fills
+ * out_log[i] = det_log(x[i]), out_exp[i] = det_exp(x[i]),
+ * out_div[i] = x[i] / y[i] (parity of IEEE division), n values. */
+int mcmc_selftest_math(mcmc_ctx *ctx, const double *x, const double *y, int n, double *out_log,
+                       double *out_exp, double *out_div);
+int mcmc_selftest_philox(mcmc_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMC_AMD_H */

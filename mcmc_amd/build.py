@@ -1,0 +1,45 @@
+"""Builds mcmc_amd/libmcmc_amd.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+In-tree, explicit hipcc line (no JIT cache): the .so travels to the GPU box.
+-ffp-contract=off is part of the numerical contract (bit-exact CPU/GPU parity).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmcmc_amd.so")
+SOURCES = ["capi.hip", "frame_kernels.hip", "chain_kernels.hip", "multiview_kernels.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "mcmc_amd.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,720 @@
+// chain_kernels.hip -- K3 chain_step (+ K5 canonical relabel / statistics).
+//
+// One independent Markov chain per 64-lane wavefront; a workgroup of WPB
+// wavefronts shares one frame.  When the frame's tables fit, they are staged
+// in LDS once per launch (fit records 96 B/superpixel, CSR columns as u16,
+// edge probabilities f64) next to each chain's private state (labels, BFS
+// queue, per-segment log-probability cache, bitsets), so a whole run of
+// burn_in+iters steps touches HBM only for statistics.  The step itself is
+// latency-bound (a data-dependent BFS), not bandwidth-bound: parallelism comes
+// from chains, and the lanes of a wave cooperate on one chain's neighbour
+// scans, segment sums and reductions.
+//
+// Restates (behaviour, not code): Problem::propose (Problem.cpp:116-224),
+// Segmentation::createComponent/selectSegment/pickSuperPixel
+// (Segmentation.cpp:10-183), Segment fits (Graph.cpp:10-138, MyMath.h:189-275),
+// jumpProbability/jump (Problem.cpp:32-74,475-487),
+// FastMetropolisHastings::iterate (MCMC.h:207-238), MCMC::run (MCMC.h:43-89),
+// Segmentation::computeHash (Segmentation.cpp:197-237), Statistics::update
+// (Statistics.h:33-47).
+//
+// Canonical order (the reference iterates std::set/std::map in heap-pointer
+// order, i.e. arbitrarily): superpixels by id; a segment is named by its
+// smallest member id.
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mc {
+
+constexpr int kLdsLimit = 160 * 1024;
+
+MC_D size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+static inline size_t h_al16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// ---- RNG: a batch of 256 draws is one Philox block per lane ----------------
+struct Rng {
+    uint32_t w0, w1, w2, w3;
+    uint32_t k0, k1, step_lo, step_hi;
+    int batch;
+};
+
+MC_D void rng_gen(Rng& g, int batch, int lane)
+{
+    u32x4 c = { g.step_lo, g.step_hi, (uint32_t)(batch * 64 + lane), kPhiloxTag };
+    u32x4 r = philox4x32_10(c, g.k0, g.k1);
+    g.w0 = r.x; g.w1 = r.y; g.w2 = r.z; g.w3 = r.w;
+    g.batch = batch;
+}
+
+// d is wave-uniform
+MC_D uint32_t rng_uniform_idx(Rng& g, uint32_t d, int lane)
+{
+    d = uni(d);
+    const int b = (int)(d >> 8);
+    if (b != g.batch) rng_gen(g, b, lane);
+    const uint32_t ws = (d >> 6) & 3u;
+    const uint32_t v = ws == 0 ? g.w0 : (ws == 1 ? g.w1 : (ws == 2 ? g.w2 : g.w3));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(d & 63u));
+}
+
+// d varies by lane (ascending with lane among lanes that `need` a draw)
+MC_D uint32_t rng_varying_idx(Rng& g, uint32_t d, bool need, int lane)
+{
+    uint32_t res = 0;
+    uint64_t m = __ballot(need);
+    while (m) {
+        const int first = __ffsll((unsigned long long)m) - 1;
+        const uint32_t dfirst = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+        const int b = (int)(dfirst >> 8);
+        if (b != g.batch) rng_gen(g, b, lane);
+        const bool mine = need && ((int)(d >> 8) == b);
+        const int src = (int)(d & 63u);
+        const uint32_t ws = (d >> 6) & 3u;
+        const uint32_t x0 = (uint32_t)__shfl((int)g.w0, src, kWave);
+        const uint32_t x1 = (uint32_t)__shfl((int)g.w1, src, kWave);
+        const uint32_t x2 = (uint32_t)__shfl((int)g.w2, src, kWave);
+        const uint32_t x3 = (uint32_t)__shfl((int)g.w3, src, kWave);
+        const uint32_t v = ws == 0 ? x0 : (ws == 1 ? x1 : (ws == 2 ? x2 : x3));
+        if (mine) res = v;
+        m &= ~__ballot(mine);
+    }
+    return res;
+}
+
+MC_D double to_unit(uint32_t x) { return (double)x / 4294967295.0; }  // rand()/RAND_MAX, inclusive of 1
+
+// idx-th set bit (ascending) of a bitset of NW words; wave-uniform result
+MC_D uint32_t nth_set_bit(const uint32_t* bits, int NW, uint32_t idx, int lane)
+{
+    uint32_t acc = 0, result = 0xFFFFFFFFu;
+    for (int wb = 0; wb < NW; wb += kWave) {
+        const int w = wb + lane;
+        const uint32_t word = w < NW ? bits[w] : 0u;
+        const int pc = __popc(word);
+        int incl = pc;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int t = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += t;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+        if (idx < acc + total) {
+            const uint32_t rel = idx - acc;
+            const uint32_t excl = (uint32_t)(incl - pc);
+            const bool here = rel >= excl && rel < (uint32_t)incl;
+            uint32_t ww = word;
+            const uint32_t k = here ? rel - excl : 0u;
+            for (uint32_t t = 0; t < k; ++t) ww &= ww - 1u;
+            const uint32_t val = (uint32_t)w * 32u + (uint32_t)(__ffs((int)ww) - 1);
+            const uint64_t hm = __ballot(here);
+            result = (uint32_t)__builtin_amdgcn_readlane((int)val, __ffsll((unsigned long long)hm) - 1);
+            break;
+        }
+        acc += total;
+    }
+    return result;
+}
+
+struct SegFit {
+    double probL;
+    int n, minid, inf_flag;
+};
+
+// ---------------------------------------------------------------------------
+// LDS carve-up (all offsets multiples of 16 B).
+// ---------------------------------------------------------------------------
+struct LdsLayout {
+    size_t fit, q, col, rowp, vlist, sv, wave0, wave_bytes, total;
+    size_t w_label, w_queue, w_segN, w_segP, w_cbits, w_nbits, w_rbits, w_rpre;
+};
+
+__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds)
+{
+    auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    LdsLayout L;
+    size_t o = 0;
+    L.fit = o; if (tab_lds) o += A((size_t)S * kFitStride * 8);
+    L.q = o; if (tab_lds) o += A((size_t)E2 * 8);
+    L.col = o; if (tab_lds) o += A((size_t)E2 * 2);
+    L.rowp = o; if (tab_lds) o += A((size_t)(S + 1) * 4);
+    L.vlist = o; o += A((size_t)S * 2);
+    L.sv = o; o += 16;
+    L.wave0 = o;
+    const size_t NW = (size_t)(S + 31) / 32;
+    size_t w = 0;
+    L.w_segP = w; w += A((size_t)S * 8);
+    L.w_label = w; w += A((size_t)S * 2);
+    L.w_queue = w; w += A((size_t)S * 2);
+    L.w_segN = w; w += A((size_t)S * 2);
+    L.w_cbits = w; w += A(NW * 4);
+    L.w_nbits = w; w += A(NW * 4);
+    L.w_rbits = w; w += A(NW * 4);
+    L.w_rpre = w; w += A(NW * 4);
+    L.wave_bytes = w;
+    L.total = o + w * (size_t)wpb;
+    return L;
+}
+
+// ---------------------------------------------------------------------------
+// The chain kernel.
+// ---------------------------------------------------------------------------
+template <int WPB, bool TAB_LDS>
+__global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int chain0 = (int)blockIdx.x * WPB;
+    const int frame = chain0 / a.chains_per_frame;
+    const int S = a.S[frame];
+    const int E2 = (int)a.E2[frame];
+    const int NW = (S + 31) / 32;
+    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS);
+
+    const double* g_fit = a.fit + (size_t)frame * a.s_max * kFitStride;
+    const double* g_q = a.q + (size_t)frame * a.e2_max;
+    const uint32_t* g_col = a.col + (size_t)frame * a.e2_max;
+    const uint32_t* g_rowp = a.rowp + (size_t)frame * (a.s_max + 1);
+    const uint8_t* g_valid = a.valid + (size_t)frame * a.s_max;
+
+    double* l_fit = reinterpret_cast<double*>(smem + L.fit);
+    double* l_q = reinterpret_cast<double*>(smem + L.q);
+    uint16_t* l_col = reinterpret_cast<uint16_t*>(smem + L.col);
+    uint32_t* l_rowp = reinterpret_cast<uint32_t*>(smem + L.rowp);
+    uint16_t* vlist = reinterpret_cast<uint16_t*>(smem + L.vlist);
+
+    // ---- stage the frame tables (block-cooperative) ----
+    if (TAB_LDS) {
+        for (int i = tid; i < S * kFitStride; i += WPB * 64) l_fit[i] = g_fit[i];
+        for (int i = tid; i < E2; i += WPB * 64) { l_q[i] = g_q[i]; l_col[i] = (uint16_t)g_col[i]; }
+        for (int i = tid; i <= S; i += WPB * 64) l_rowp[i] = g_rowp[i];
+    }
+    // list of superpixels that passed the A1 filter, ascending (wave 0)
+    int* s_Sv = reinterpret_cast<int*>(smem + L.sv);
+    if (wave == 0) {
+        int cnt = 0;
+        for (int b = 0; b < S; b += kWave) {
+            const int i = b + lane;
+            const bool ok = i < S && g_valid[i];
+            const uint64_t m = __ballot(ok);
+            if (ok) vlist[cnt + mbcnt(m)] = (uint16_t)i;
+            cnt += __popcll((unsigned long long)m);
+        }
+        if (lane == 0) *s_Sv = cnt;
+    }
+    __syncthreads();
+    const int Sv = *s_Sv;
+    const int chain = chain0 + wave;
+    if (chain >= a.n_chains || Sv == 0) return;
+
+    // ---- table accessors: LDS or HBM/L2 ----
+    const double* fit; const double* qv; const uint32_t* rowp;
+    if constexpr (TAB_LDS) { fit = l_fit; qv = l_q; rowp = l_rowp; }
+    else { fit = g_fit; qv = g_q; rowp = g_rowp; }
+    auto colAt = [&](uint32_t e) -> uint32_t {
+        if constexpr (TAB_LDS) return (uint32_t)l_col[e]; else return g_col[e];
+    };
+
+    // ---- wave-private state ----
+    unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
+    double* segP = reinterpret_cast<double*>(wbase + L.w_segP);
+    uint16_t* label = reinterpret_cast<uint16_t*>(wbase + L.w_label);
+    uint16_t* queue = reinterpret_cast<uint16_t*>(wbase + L.w_queue);
+    uint16_t* segN = reinterpret_cast<uint16_t*>(wbase + L.w_segN);
+    uint32_t* cbits = reinterpret_cast<uint32_t*>(wbase + L.w_cbits);
+    uint32_t* nbits = reinterpret_cast<uint32_t*>(wbase + L.w_nbits);
+    uint32_t* rbits = reinterpret_cast<uint32_t*>(wbase + L.w_rbits);
+    uint32_t* rpre = reinterpret_cast<uint32_t*>(wbase + L.w_rpre);
+
+    uint16_t* g_label = a.label + (size_t)chain * a.s_max;
+    double* g_segP = a.segP + (size_t)chain * a.s_max;
+    uint16_t* g_segN = a.segN + (size_t)chain * a.s_max;
+    for (int i = lane; i < S; i += kWave) { label[i] = g_label[i]; segP[i] = g_segP[i]; segN[i] = g_segN[i]; }
+    for (int w = lane; w < NW; w += kWave) { cbits[w] = 0u; nbits[w] = 0u; }
+
+    double energy = a.energy[chain], best_energy = a.best_energy[chain];
+    uint64_t state_hash = a.state_hash[chain], trace_hash = a.trace_hash[chain];
+    uint64_t n_accept = a.n_accept[chain];
+    uint64_t n_case0 = a.n_case[(size_t)chain * 3 + 0], n_case1 = a.n_case[(size_t)chain * 3 + 1],
+             n_case2 = a.n_case[(size_t)chain * 3 + 2];
+    int status = a.status[chain];
+    uint64_t top_count = a.top_count[chain], top_hash = a.top_hash[chain], overflow = a.overflow[chain];
+    uint64_t dwell = 0;
+
+    const double var = a.var, nsp = a.new_seg_prob;
+    const double log_var = det_log(var);
+    const double inv2var_den = 2.0 * var;
+
+    Rng g;
+    g.k0 = a.seed; g.k1 = a.chain_offset + (uint32_t)chain;
+
+    unsigned long long* marg = a.marg + (size_t)frame * a.s_max * a.lmax;
+    unsigned long long* vh = a.visit_hash + (size_t)chain * a.hcap;
+    unsigned long long* vc = a.visit_count + (size_t)chain * a.hcap;
+
+    // Book `dwell` visits of the CURRENT state: Statistics::update (Statistics.h:33-47)
+    // and the label-marginal histogram.  The state only changes on an accepted
+    // split/merge, so visits are booked when the chain leaves a state.
+    auto flush_stats = [&]() {
+        if (dwell == 0) return;
+        // visit table: open addressing, count == 0 marks an empty slot
+        uint64_t cnt = 0;
+        int snap = 0;
+        if (lane == 0) {
+            const uint32_t h0 = (uint32_t)(state_hash % (uint64_t)a.hcap);
+            bool done = false;
+            for (int p = 0; p < a.hcap && !done; ++p) {
+                const uint32_t idx = (h0 + (uint32_t)p) % (uint32_t)a.hcap;
+                const uint64_t c = vc[idx];
+                if (c == 0) { vh[idx] = state_hash; vc[idx] = dwell; cnt = dwell; done = true; }
+                else if (vh[idx] == state_hash) { cnt = c + dwell; vc[idx] = cnt; done = true; }
+            }
+            if (!done) overflow += dwell;
+            else if (cnt > top_count || (cnt == top_count && state_hash < top_hash)) {
+                snap = (state_hash != top_hash || top_count == 0) ? 1 : 0;
+                top_count = cnt; top_hash = state_hash;
+            }
+        }
+        snap = uni(snap);
+        top_count = (uint64_t)__shfl((unsigned long long)top_count, 0, kWave);
+        top_hash = (uint64_t)__shfl((unsigned long long)top_hash, 0, kWave);
+        overflow = (uint64_t)__shfl((unsigned long long)overflow, 0, kWave);
+        if (snap) {
+            uint16_t* tl = a.top_label + (size_t)chain * a.s_max;
+            for (int i = lane; i < S; i += kWave) tl[i] = label[i];
+        }
+        // first-appearance rank of every root (Segmentation.cpp:210-227)
+        uint32_t running = 0;
+        for (int b = 0; b < S; b += kWave) {
+            const int i = b + lane;
+            const bool root = i < S && label[i] == (uint16_t)i;
+            const uint64_t m = __ballot(root);
+            if (lane == 0) {
+                rbits[(b >> 5)] = (uint32_t)m; rpre[(b >> 5)] = running;
+                if ((b >> 5) + 1 < NW) { rbits[(b >> 5) + 1] = (uint32_t)(m >> 32); rpre[(b >> 5) + 1] = running + (uint32_t)__popc((uint32_t)m); }
+            }
+            running += (uint32_t)__popcll((unsigned long long)m);
+        }
+        for (int i = lane; i < S; i += kWave) {
+            const uint32_t Lb = label[i];
+            if (Lb == kNoLabel) continue;
+            const uint32_t rank = rpre[Lb >> 5] + (uint32_t)__popc(rbits[Lb >> 5] & ((1u << (Lb & 31u)) - 1u));
+            const uint32_t bin = rank < (uint32_t)a.lmax ? rank : (uint32_t)a.lmax - 1u;
+            atomicAdd(marg + (size_t)i * a.lmax + bin, (unsigned long long)dwell);
+        }
+        dwell = 0;
+    };
+
+    const unsigned long long total = a.burn_in + a.iters;
+    for (unsigned long long ts = 0; ts < total; ++ts) {
+        const unsigned long long t = a.step0 + ts;
+        uint8_t tb = 0xFF;
+        if (status == 0) {
+            g.step_lo = (uint32_t)t; g.step_hi = (uint32_t)(t >> 32); g.batch = -1;
+            uint32_t nd = 0;
+
+            // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161)
+            const uint32_t start = vlist[rng_uniform_idx(g, nd, lane) % (uint32_t)Sv];
+            nd += 2;
+            const uint32_t orig = label[start];
+
+            // ---- createComponent BFS (Segmentation.cpp:74-120) ----
+            if (lane == 0) { queue[0] = (uint16_t)start; cbits[start >> 5] = 1u << (start & 31u); }
+            uint32_t qn = 1;
+            for (uint32_t head = 0; head < qn; ++head) {
+                const uint32_t i = uni((uint32_t)queue[head]);
+                const uint32_t rs = uni(rowp[i]), re = uni(rowp[i + 1]);
+                for (uint32_t base = rs; base < re; base += kWave) {
+                    const uint32_t e = base + (uint32_t)lane;
+                    const bool act = e < re;
+                    const uint32_t j = act ? colAt(e) : 0u;
+                    const double qe = act ? qv[e] : -1.0;
+                    const bool live = act && !(qe < 0.0);
+                    const bool inC = (cbits[j >> 5] >> (j & 31u)) & 1u;
+                    const uint32_t lj = label[j];
+                    const bool elig = live && !inC && lj == orig;
+                    const bool oth = live && !inC && lj != orig;
+                    if (oth) atomicOr(&nbits[lj >> 5], 1u << (lj & 31u));
+                    const uint64_t em = __ballot(elig);
+                    if (em) {
+                        const uint32_t xr = rng_varying_idx(g, nd + (uint32_t)mbcnt(em), elig, lane);
+                        nd += (uint32_t)__popcll((unsigned long long)em);
+                        const bool join = elig && (to_unit(xr) < qe);  // strict (Segmentation.cpp:110)
+                        const uint64_t jm = __ballot(join);
+                        if (join) {
+                            queue[qn + (uint32_t)mbcnt(jm)] = (uint16_t)j;
+                            atomicOr(&cbits[j >> 5], 1u << (j & 31u));
+                        }
+                        qn += (uint32_t)__popcll((unsigned long long)jm);
+                    }
+                }
+            }
+            const uint32_t csize = qn;
+            const bool same = csize == (uint32_t)segN[orig];  // Segmentation.cpp:19
+
+            // ---- selectSegment (Segmentation.cpp:10-57) ----
+            const double u1 = to_unit(rng_uniform_idx(g, nd, lane)); nd += 1;
+            int kase; uint32_t next = orig; double ratio;
+            if (!same && u1 < nsp) { kase = 1; ratio = nsp; }
+            else {
+                int nnl = 0;
+                for (int w = lane; w < NW; w += kWave) nnl += __popc(nbits[w]);
+                const uint32_t numSeg = (uint32_t)wave_sum_i32(nnl) + 1u;
+                const double existing = same ? 1.0 : (1.0 - nsp);
+                const uint32_t idx = rng_uniform_idx(g, nd, lane) % numSeg; nd += 1;
+                if (idx == numSeg - 1u) { kase = 0; next = orig; }
+                else { kase = 2; next = nth_set_bit(nbits, NW, idx, lane); }
+                ratio = existing / (double)numSeg;
+            }
+
+            double targetL = 1.0, prop = ratio;  // Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic)
+            SegFit f1 = { 0.0, 0, 0, 0 }, f2 = { 0.0, 0, 0, 0 };
+            int st = 0;
+            const bool have1 = !(kase == 2 && same);
+            if (kase != 0) {
+                // separation / merge products over the component's cut edges
+                // (Segmentation.cpp:127-146; Graph.cpp:10-33), wave order over the queue
+                double ps = 1.0, pm = 1.0;
+                for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) {
+                    const uint32_t i = queue[h];
+                    const uint32_t rs = rowp[i], re = rowp[i + 1];
+                    for (uint32_t e = rs; e < re; ++e) {
+                        const double qe = qv[e];
+                        if (qe < 0.0) continue;
+                        const uint32_t j = colAt(e);
+                        const uint32_t lj = label[j];
+                        if (lj == orig) { if (!((cbits[j >> 5] >> (j & 31u)) & 1u)) ps = ps * (1.0 - qe); }
+                        else if (kase == 2 && lj == next) pm = pm * (1.0 - qe);
+                    }
+                }
+                const double sep = wave_prod_f64(ps);
+
+                // ---- fused fits of sB2 (code 2) and sB1 (code 1): pass 1, exact sums ----
+                double s2[9], s1[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { s2[k] = 0.0; s1[k] = 0.0; }
+                int n2 = 0, n1 = 0, m2 = 0x7FFFFFFF, m1 = 0x7FFFFFFF;
+                for (int i = lane; i < S; i += kWave) {
+                    const uint32_t li = label[i];
+                    if (li == kNoLabel) continue;
+                    const bool inC = (cbits[i >> 5] >> (i & 31)) & 1u;
+                    int m;
+                    if (kase == 1) m = inC ? 2 : (li == orig ? 1 : 0);
+                    else m = (inC || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
+                    if (m == 2) {
+                        const double* f = fit + (size_t)i * kFitStride;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) s2[k] += f[k];
+                        n2++; m2 = min(m2, i);
+                    } else if (m == 1) {
+                        const double* f = fit + (size_t)i * kFitStride;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) s1[k] += f[k];
+                        n1++; m1 = min(m1, i);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s2[k] = wave_sum_f64(s2[k]);  // integer-valued: exact, order-free
+                n2 = wave_sum_i32(n2); m2 = wave_min_i32(m2);
+                if (have1) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) s1[k] = wave_sum_f64(s1[k]);
+                    n1 = wave_sum_i32(n1); m1 = wave_min_i32(m1);
+                }
+                Vec3 th2, d2, th1 = { 0, 0, 0 }, d1 = { 1, 1, 1 };
+                {
+                    Sym3 A2 = { s2[0], s2[1], s2[2], s2[3], s2[4], s2[5] };
+                    Vec3 r2 = { s2[6], s2[7], s2[8] };
+                    ldl3(A2, r2, th2, d2);
+                }
+                if (have1) {
+                    Sym3 A1 = { s1[0], s1[1], s1[2], s1[3], s1[4], s1[5] };
+                    Vec3 r1 = { s1[6], s1[7], s1[8] };
+                    ldl3(A1, r1, th1, d1);
+                }
+                // ---- pass 2: factor errors at the fused mean (MyMath.h:247-252), wave order ----
+                double e2p = 0.0, e1p = 0.0;
+                for (int i = lane; i < S; i += kWave) {
+                    const uint32_t li = label[i];
+                    if (li == kNoLabel) continue;
+                    const bool inC = (cbits[i >> 5] >> (i & 31)) & 1u;
+                    int m;
+                    if (kase == 1) m = inC ? 2 : (li == orig ? 1 : 0);
+                    else m = (inC || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
+                    if (m == 2) e2p += member_quad(fit + (size_t)i * kFitStride, th2);
+                    else if (m == 1) e1p += member_quad(fit + (size_t)i * kFitStride, th1);
+                }
+                const double err2 = wave_sum_f64(e2p) / inv2var_den;
+                f2.probL = segment_logprob(err2, d2, log_var, &f2.inf_flag);
+                f2.n = n2; f2.minid = m2;
+                if (have1) {
+                    const double err1 = wave_sum_f64(e1p) / inv2var_den;
+                    f1.probL = segment_logprob(err1, d1, log_var, &f1.inf_flag);
+                    f1.n = n1; f1.minid = m1;
+                }
+                if (kase == 1) prop = ratio * (1.0 / sep);              // Problem.cpp:188
+                else prop = ratio * (wave_prod_f64(pm) / sep);          // Problem.cpp:206
+                // jumpProbability (Problem.cpp:475-487)
+                const double sB2_sA1 = f2.probL - segP[orig];
+                const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? segP[next] : 0.0);
+                targetL = sB2_sA1 + sB1_sA2;
+                if (f1.inf_flag || f2.inf_flag) st = -5;
+                if (targetL != targetL || prop != prop) st = -4;        // Problem.cpp:216-217
+            }
+
+            // ---- FastMetropolisHastings::iterate (MCMC.h:218-227) ----
+            const double aL = targetL + det_log(prop);
+            const double acc = det_exp(aL);
+            const double r = to_unit(rng_uniform_idx(g, nd, lane)); nd += 1;  // always drawn
+            bool accept = true;
+            if (aL < 0.0) { if (r > acc) accept = false; }
+            if (st != 0) { accept = false; status = st; }
+
+            uint32_t newlab = next;
+            if (accept && kase != 0) {
+                flush_stats();  // leaving the current state
+                // jump (Problem.cpp:32-74) with smallest-member naming
+                const uint32_t L2 = (uint32_t)f2.minid, L1 = (uint32_t)(f1.n ? f1.minid : 0);
+                uint64_t dh = 0;
+                for (int i = lane; i < S; i += kWave) {
+                    const uint32_t li = label[i];
+                    if (li == kNoLabel) continue;
+                    const bool inC = (cbits[i >> 5] >> (i & 31)) & 1u;
+                    int m;
+                    if (kase == 1) m = inC ? 2 : (li == orig ? 1 : 0);
+                    else m = (inC || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
+                    const uint32_t nl = m == 2 ? L2 : (m == 1 ? L1 : li);
+                    if (nl != li) {
+                        dh += mix64(((uint64_t)i << 32) | nl) - mix64(((uint64_t)i << 32) | li);
+                        label[i] = (uint16_t)nl;
+                    }
+                }
+                state_hash += wave_sum_u64(dh);
+                if (lane == 0) {
+                    segP[L2] = f2.probL; segN[L2] = (uint16_t)f2.n;
+                    if (f1.n) { segP[L1] = f1.probL; segN[L1] = (uint16_t)f1.n; }
+                }
+                energy += targetL;
+                if (energy > best_energy) {
+                    best_energy = energy;
+                    uint16_t* bl = a.best_label + (size_t)chain * a.s_max;
+                    for (int i = lane; i < S; i += kWave) bl[i] = label[i];
+                }
+                newlab = L2;
+            }
+            if (accept) n_accept++;
+            if (kase == 0) n_case0++; else if (kase == 1) n_case1++; else n_case2++;
+
+            // clear scratch bitsets
+            for (int w = lane; w < NW; w += kWave) { cbits[w] = 0u; nbits[w] = 0u; }
+
+            tb = (uint8_t)((accept ? 1 : 0) | (kase << 1));
+            const uint64_t wd = (uint64_t)tb | ((uint64_t)start << 8) | ((uint64_t)csize << 24) | ((uint64_t)newlab << 40);
+            trace_hash = mix64(mix64(trace_hash ^ wd) ^ state_hash);
+        }
+        if (a.trace && lane == 0) a.trace[(size_t)chain * a.trace_stride + ts] = tb;
+        if (ts >= a.burn_in && status == 0) dwell++;
+    }
+    flush_stats();
+
+    // ---- write the chain back ----
+    for (int i = lane; i < S; i += kWave) { g_label[i] = label[i]; g_segP[i] = segP[i]; g_segN[i] = segN[i]; }
+    if (lane == 0) {
+        a.energy[chain] = energy; a.best_energy[chain] = best_energy;
+        a.state_hash[chain] = state_hash; a.trace_hash[chain] = trace_hash;
+        a.n_accept[chain] = n_accept;
+        a.n_case[(size_t)chain * 3 + 0] = n_case0; a.n_case[(size_t)chain * 3 + 1] = n_case1;
+        a.n_case[(size_t)chain * 3 + 2] = n_case2;
+        a.status[chain] = status;
+        a.top_count[chain] = top_count; a.top_hash[chain] = top_hash; a.overflow[chain] = overflow;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Problem::initializeState (Problem.cpp:447-473): every superpixel that passed
+// the filter in ONE segment.  One wavefront per chain.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void chain_init_kernel(ChainArgs a)
+{
+    const int chain = (int)blockIdx.x;
+    const int lane = lane_id();
+    const int frame = chain / a.chains_per_frame;
+    const int S = a.S[frame];
+    const double* fit = a.fit + (size_t)frame * a.s_max * kFitStride;
+    const uint8_t* valid = a.valid + (size_t)frame * a.s_max;
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    int n = 0, mn = 0x7FFFFFFF;
+    for (int i = lane; i < S; i += kWave) {
+        if (!valid[i]) continue;
+        const double* f = fit + (size_t)i * kFitStride;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k] += f[k];
+        n++; mn = min(mn, i);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum_f64(s[k]);
+    n = wave_sum_i32(n); mn = wave_min_i32(mn);
+    double p = 0.0; int inf_flag = 0;
+    if (n > 0) {
+        Sym3 A = { s[0], s[1], s[2], s[3], s[4], s[5] };
+        Vec3 r = { s[6], s[7], s[8] }, th, d;
+        ldl3(A, r, th, d);
+        double ep = 0.0;
+        for (int i = lane; i < S; i += kWave)
+            if (valid[i]) ep += member_quad(fit + (size_t)i * kFitStride, th);
+        p = segment_logprob(wave_sum_f64(ep) / (2.0 * a.var), d, det_log(a.var), &inf_flag);
+    }
+    const uint16_t root = n > 0 ? (uint16_t)mn : (uint16_t)0;
+    uint16_t* lab = a.label + (size_t)chain * a.s_max;
+    uint16_t* bl = a.best_label + (size_t)chain * a.s_max;
+    uint16_t* tl = a.top_label + (size_t)chain * a.s_max;
+    double* segP = a.segP + (size_t)chain * a.s_max;
+    uint16_t* segN = a.segN + (size_t)chain * a.s_max;
+    uint64_t h = 0;
+    for (int i = lane; i < a.s_max; i += kWave) {
+        const bool ok = i < S && valid[i];
+        const uint16_t l = ok ? root : kNoLabel;
+        lab[i] = l; bl[i] = l; tl[i] = l;
+        segP[i] = (ok && i == (int)root) ? p : 0.0;
+        segN[i] = (ok && i == (int)root) ? (uint16_t)n : (uint16_t)0;
+        if (ok) h += mix64(((uint64_t)i << 32) | l);
+    }
+    h = wave_sum_u64(h);
+    for (int i = lane; i < a.hcap; i += kWave) {
+        a.visit_hash[(size_t)chain * a.hcap + i] = 0ull;
+        a.visit_count[(size_t)chain * a.hcap + i] = 0ull;
+    }
+    if (lane == 0) {
+        a.energy[chain] = p; a.best_energy[chain] = p;
+        a.state_hash[chain] = h; a.trace_hash[chain] = 0ull;
+        a.n_accept[chain] = 0ull;
+        a.n_case[(size_t)chain * 3 + 0] = 0ull; a.n_case[(size_t)chain * 3 + 1] = 0ull;
+        a.n_case[(size_t)chain * 3 + 2] = 0ull;
+        a.status[chain] = inf_flag ? -5 : (n > 0 ? 0 : -7);
+        a.top_count[chain] = 0ull; a.top_hash[chain] = 0ull; a.overflow[chain] = 0ull;
+    }
+}
+
+// Segmentation::computeProbability (Segmentation.cpp:185-195): sum of the cached
+// segment log-probabilities, wave order over roots by id.
+__global__ __launch_bounds__(64) void chain_energy_kernel(ChainArgs a, double* out)
+{
+    const int chain = (int)blockIdx.x;
+    const int lane = lane_id();
+    const int frame = chain / a.chains_per_frame;
+    const int S = a.S[frame];
+    const uint16_t* lab = a.label + (size_t)chain * a.s_max;
+    const double* segP = a.segP + (size_t)chain * a.s_max;
+    double part = 0.0;
+    for (int i = lane; i < S; i += kWave)
+        if (lab[i] == (uint16_t)i) part += segP[i];
+    const double e = wave_sum_f64(part);
+    if (lane == 0) out[chain] = e;
+}
+
+// First-appearance relabel (Segmentation.cpp:197-233) of n_chains label rows.
+__global__ __launch_bounds__(64) void canonical_labels_kernel(const uint16_t* src, const int* S_arr, int s_max,
+                                                              int chains_per_frame, uint16_t* dst)
+{
+    extern __shared__ uint32_t sh[];  // rbits[NW] | rpre[NW]
+    const int chain = (int)blockIdx.x;
+    const int lane = lane_id();
+    const int S = S_arr[chain / chains_per_frame];
+    const int NW = (s_max + 63) / 64 * 2;
+    uint32_t* rbits = sh;
+    uint32_t* rpre = sh + NW;
+    const uint16_t* lab = src + (size_t)chain * s_max;
+    uint16_t* out = dst + (size_t)chain * s_max;
+    uint32_t running = 0;
+    for (int b = 0; b < S; b += kWave) {
+        const int i = b + lane;
+        const bool root = i < S && lab[i] == (uint16_t)i;
+        const uint64_t m = __ballot(root);
+        if (lane == 0) {
+            rbits[b >> 5] = (uint32_t)m; rpre[b >> 5] = running;
+            rbits[(b >> 5) + 1] = (uint32_t)(m >> 32); rpre[(b >> 5) + 1] = running + (uint32_t)__popc((uint32_t)m);
+        }
+        running += (uint32_t)__popcll((unsigned long long)m);
+    }
+    __syncthreads();
+    for (int i = lane; i < s_max; i += kWave) {
+        uint16_t o = kNoLabel;
+        if (i < S) {
+            const uint32_t Lb = lab[i];
+            if (Lb != kNoLabel)
+                o = (uint16_t)(rpre[Lb >> 5] + (uint32_t)__popc(rbits[Lb >> 5] & ((1u << (Lb & 31u)) - 1u)));
+        }
+        out[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL(chain_init_kernel, dim3(a.n_chains), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int WPB, bool TAB>
+static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int blocks = (a.n_chains + WPB - 1) / WPB;
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out)
+{
+    const size_t cap = kLdsLimit - 64;
+    const int wpbs[3] = { 4, 2, 1 };
+    for (int tab = 1; tab >= 0; --tab) {
+        for (int wi = 0; wi < 3; ++wi) {
+            const int wpb = wpbs[wi];
+            if (a.chains_per_frame % wpb) continue;
+            const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0);
+            if (L.total > cap) continue;
+            if (variant_out) *variant_out = tab * 10 + wpb;
+            if (tab) {
+                if (wpb == 4) return launch_variant<4, true>(a, s_used_max, e2_used_max, L.total, st);
+                if (wpb == 2) return launch_variant<2, true>(a, s_used_max, e2_used_max, L.total, st);
+                return launch_variant<1, true>(a, s_used_max, e2_used_max, L.total, st);
+            } else {
+                if (wpb == 4) return launch_variant<4, false>(a, s_used_max, e2_used_max, L.total, st);
+                if (wpb == 2) return launch_variant<2, false>(a, s_used_max, e2_used_max, L.total, st);
+                return launch_variant<1, false>(a, s_used_max, e2_used_max, L.total, st);
+            }
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_chain_energy(const ChainArgs& a, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(chain_energy_kernel, dim3(a.n_chains), dim3(64), 0, st, a, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_canonical_labels(const uint16_t* src, const uint8_t* /*valid*/, const int* S, int s_max,
+                                   int n_chains, int chains_per_frame, uint16_t* dst, hipStream_t st)
+{
+    const int NW = (s_max + 63) / 64 * 2;
+    hipLaunchKernelGGL(canonical_labels_kernel, dim3(n_chains), dim3(64), (size_t)NW * 8, st, src, S, s_max,
+                       chains_per_frame, dst);
+    return hipGetLastError();
+}
+
+}  // namespace mc

@@ -1,0 +1,89 @@
+// kernels.hpp -- argument blocks and launchers shared by the C ABI and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mc {
+
+struct MomentArgs {
+    const int16_t* disp;       // [F][H][W]
+    const uint16_t* label;     // [F][H][W]
+    const int* S;              // [F] superpixels per frame
+    unsigned long long* mom;   // [F][s_max][10] int64 bit patterns
+    size_t frame_stride;       // pixels per frame
+    int W, H, s_max, bands, first_frame;
+};
+
+struct FitArgs {
+    const unsigned long long* mom;
+    const int* S;
+    double* fit;               // [F][s_max][12]
+    uint8_t* valid;            // [F][s_max]
+    double* local_err;         // [F][s_max]
+    double var;
+    int W, H, s_max, first_frame;
+};
+
+struct EdgeArgs {
+    const double* fit;
+    const uint8_t* valid;
+    const uint32_t* rowp;      // [F][s_max+1]
+    const uint32_t* col;       // [F][e2_max]
+    const int* S;
+    const uint32_t* E2;        // [F]
+    double* q;                 // [F][e2_max]
+    int* status;               // [F] bit0 NaN ratio, bit1 inf energy
+    double var;
+    int s_max, e2_max, first_frame;
+};
+
+struct SegArgs {
+    const double* fit;         // one frame
+    const uint8_t* mem;        // [S]
+    double* out;               // probL err theta3 inf_flag
+    double var;
+    int S;
+};
+
+// Per-chain state in HBM between launches (chain-major, stride s_max).
+struct ChainArgs {
+    // frame tables
+    const double* fit; const uint8_t* valid; const uint32_t* rowp; const uint32_t* col;
+    const double* q; const int* S; const uint32_t* E2;
+    int s_max, e2_max;
+    // chains
+    int n_chains, chains_per_frame;
+    uint32_t seed, chain_offset;
+    unsigned long long step0, burn_in, iters;
+    double var, new_seg_prob;
+    uint16_t* label;           // [C][s_max] min-id labels
+    double* segP;              // [C][s_max]
+    uint16_t* segN;            // [C][s_max]
+    double* energy; double* best_energy;
+    uint16_t* best_label; uint16_t* top_label;
+    unsigned long long* state_hash; unsigned long long* trace_hash;
+    unsigned long long* n_accept; unsigned long long* n_case; // [C][3]
+    int* status;
+    unsigned long long* visit_hash; unsigned long long* visit_count; // [C][hcap]
+    unsigned long long* overflow; unsigned long long* top_count; unsigned long long* top_hash;
+    unsigned long long* marg;  // [F][s_max][lmax]
+    unsigned long long* dwell; // [C] post-burn-in steps spent in the current state, not yet booked
+    uint8_t* trace; unsigned long long trace_stride; // optional
+    int hcap, lmax;
+};
+
+hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, bool generic, hipStream_t st);
+hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st);
+hipError_t launch_edge_prob(const EdgeArgs& a, int n_frames, hipStream_t st);
+hipError_t launch_segment_prob(const SegArgs& a, hipStream_t st);
+hipError_t launch_selftest_math(const double* x, const double* y, int n, double* ol, double* oe, double* od, hipStream_t st);
+hipError_t launch_selftest_philox(const uint32_t* ck, uint32_t* out, hipStream_t st);
+
+// chain kernel: returns hipErrorInvalidValue if the per-chain state does not fit LDS
+hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st);
+hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out);
+hipError_t launch_chain_energy(const ChainArgs& a, double* out, hipStream_t st);
+hipError_t launch_canonical_labels(const uint16_t* src, const uint8_t* valid, const int* S, int s_max,
+                                   int n_chains, int chains_per_frame, uint16_t* dst, hipStream_t st);
+
+}  // namespace mc

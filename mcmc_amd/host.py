@@ -1,0 +1,271 @@
+"""ctypes binding of include/mcmc_amd.h (libmcmc_amd.so).
+
+Thin: every method is one C-ABI call plus numpy buffer plumbing.  There is no
+CPU fallback -- if the HIP library is missing or a call fails this raises.
+The C++ adapter with the reference's Problem / Segmentation / MCMC<PROBLEM>
+shapes lives in include/mcmc_amd_adapter.hpp; this module is what tests/ and
+bench.py drive.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmcmc_amd.so")
+
+NOLABEL = 0xFFFF
+K_MOMENTS, K_LOCAL_FIT, K_EDGE_PROB, K_CHAIN = 0, 1, 2, 3
+
+ERRORS = {-1: "MCMC_E_BADARG", -2: "MCMC_E_DEVICE", -3: "MCMC_E_STATE", -4: "MCMC_E_NAN_RATIO",
+          -5: "MCMC_E_INF_ENERGY", -6: "MCMC_E_TOO_LARGE", -7: "MCMC_E_NOSUPERPIXELS"}
+
+
+class McmcError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"{ERRORS.get(code, code)}: {text}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("disparity_variance", C.c_double),
+                ("new_segment_prob", C.c_double), ("marginal_bins", C.c_int32),
+                ("visit_capacity", C.c_int32)]
+
+
+_lib = None
+
+
+def _ptr(a, dtype):
+    if a is None:
+        return None
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"], (a.dtype, dtype)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load():
+    """Load libmcmc_amd.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                          " (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i, u32, u64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
+    sig = {
+        "mcmc_default_params": (None, [C.POINTER(Params)]),
+        "mcmc_ctx_create": (i, [i, C.POINTER(Params), C.POINTER(vp)]),
+        "mcmc_ctx_destroy": (i, [vp]),
+        "mcmc_last_error": (C.c_char_p, [vp]),
+        "mcmc_ctx_set_stream": (i, [vp, vp]),
+        "mcmc_ctx_synchronize": (i, [vp]),
+        "mcmc_version": (C.c_char_p, []),
+        "mcmc_frames_alloc": (i, [vp, i, i, i]),
+        "mcmc_frame_upload": (i, [vp, i, vp, vp, i]),
+        "mcmc_frame_upload_device": (i, [vp, i, vp, vp, i]),
+        "mcmc_frame_set_graph": (i, [vp, i, vp, vp, u32]),
+        "mcmc_frames_moments": (i, [vp, i, i]),
+        "mcmc_frames_edge_probs": (i, [vp, i, i]),
+        "mcmc_frame_get_moments": (i, [vp, i, vp]),
+        "mcmc_frame_get_local_fit": (i, [vp, i, vp, vp, vp]),
+        "mcmc_frame_get_edge_probs": (i, [vp, i, vp]),
+        "mcmc_segment_probability": (i, [vp, i, vp, i, C.POINTER(dbl), vp, C.POINTER(dbl)]),
+        "mcmc_chains_init": (i, [vp, i, i, u32, u32]),
+        "mcmc_chains_run": (i, [vp, u64, u64]),
+        "mcmc_chains_set_trace": (i, [vp, u64]),
+        "mcmc_chains_get_trace": (i, [vp, vp]),
+        "mcmc_chains_get_labels": (i, [vp, i, i, vp]),
+        "mcmc_chains_get_scalars": (i, [vp] + [vp] * 10),
+        "mcmc_chains_get_visits": (i, [vp, vp, vp]),
+        "mcmc_frame_get_marginals": (i, [vp, i, vp]),
+        "mcmc_chains_recompute_energy": (i, [vp, vp]),
+        "mcmc_last_kernel_ms": (dbl, [vp, i]),
+        "mcmc_set_timing": (i, [vp, i]),
+        "mcmc_selftest_math": (i, [vp, vp, vp, i, vp, vp, vp]),
+        "mcmc_selftest_philox": (i, [vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class Context:
+    """One context per (thread, GPU): frames resident in HBM plus chains over them."""
+
+    def __init__(self, width=640, height=480, device=0, disparity_variance=7.0, new_segment_prob=0.8,
+                 marginal_bins=64, visit_capacity=256):
+        L = load()
+        self.L = L
+        self.p = Params(width, height, disparity_variance, new_segment_prob, marginal_bins, visit_capacity)
+        self.h = C.c_void_p()
+        rc = L.mcmc_ctx_create(device, C.byref(self.p), C.byref(self.h))
+        if rc != 0:
+            raise McmcError(rc, "mcmc_ctx_create failed (no GPU, or bad parameters)")
+        self.width, self.height = width, height
+        self.n_frames = self.s_max = self.e2_max = 0
+        self.S = []
+        self.E2 = []
+        self.n_chains = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise McmcError(rc, self.L.mcmc_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.mcmc_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- frames
+    def frames_alloc(self, n_frames, s_max, e2_max):
+        self._ck(self.L.mcmc_frames_alloc(self.h, n_frames, s_max, e2_max))
+        self.n_frames, self.s_max, self.e2_max = n_frames, s_max, e2_max
+        self.S = [0] * n_frames
+        self.E2 = [0] * n_frames
+
+    def frame_upload(self, frame, disp, label, n_superpixels):
+        disp = np.ascontiguousarray(disp, np.int16)
+        label = np.ascontiguousarray(label, np.uint16)
+        assert disp.size == self.width * self.height == label.size
+        self._ck(self.L.mcmc_frame_upload(self.h, frame, _ptr(disp, np.int16), _ptr(label, np.uint16),
+                                          n_superpixels))
+        self.S[frame] = n_superpixels
+
+    def frame_upload_device(self, frame, disp_ptr, label_ptr, n_superpixels):
+        self._ck(self.L.mcmc_frame_upload_device(self.h, frame, C.c_void_p(disp_ptr), C.c_void_p(label_ptr),
+                                                 n_superpixels))
+        self.S[frame] = n_superpixels
+
+    def frame_set_graph(self, frame, row_ptr, col):
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint32)
+        col = np.ascontiguousarray(col, np.uint32)
+        self._ck(self.L.mcmc_frame_set_graph(self.h, frame, _ptr(row_ptr, np.uint32), _ptr(col, np.uint32),
+                                             col.size))
+        self.E2[frame] = int(col.size)
+
+    def frames_moments(self, first=0, count=None):
+        self._ck(self.L.mcmc_frames_moments(self.h, first, self.n_frames - first if count is None else count))
+
+    def frames_edge_probs(self, first=0, count=None):
+        self._ck(self.L.mcmc_frames_edge_probs(self.h, first, self.n_frames - first if count is None else count))
+
+    def moments(self, frame):
+        out = np.zeros((self.S[frame], 10), np.int64)
+        self._ck(self.L.mcmc_frame_get_moments(self.h, frame, _ptr(out, np.int64)))
+        return out
+
+    def local_fit(self, frame):
+        S = self.S[frame]
+        fit = np.zeros((S, 12)); valid = np.zeros(S, np.uint8); lerr = np.zeros(S)
+        self._ck(self.L.mcmc_frame_get_local_fit(self.h, frame, _ptr(fit, np.float64), _ptr(valid, np.uint8),
+                                                 _ptr(lerr, np.float64)))
+        return fit, valid, lerr
+
+    def edge_probs(self, frame):
+        q = np.zeros(self.E2[frame])
+        self._ck(self.L.mcmc_frame_get_edge_probs(self.h, frame, _ptr(q, np.float64)))
+        return q
+
+    def segment_probability(self, frame, members):
+        m = np.ascontiguousarray(members, np.uint32)
+        p = C.c_double(); e = C.c_double(); th = np.zeros(3)
+        self._ck(self.L.mcmc_segment_probability(self.h, frame, _ptr(m, np.uint32), m.size, C.byref(p),
+                                                 _ptr(th, np.float64), C.byref(e)))
+        return p.value, th, e.value
+
+    # ---- chains
+    def chains_init(self, n_chains, chains_per_frame=None, seed=1, chain_offset=0):
+        cpf = n_chains if chains_per_frame is None else chains_per_frame
+        self._ck(self.L.mcmc_chains_init(self.h, n_chains, cpf, seed, chain_offset))
+        self.n_chains = n_chains
+        self.chains_per_frame = cpf
+
+    def chains_set_trace(self, capacity_steps):
+        self._ck(self.L.mcmc_chains_set_trace(self.h, capacity_steps))
+
+    def chains_run(self, burn_in, iters, sync=True):
+        self._ck(self.L.mcmc_chains_run(self.h, burn_in, iters))
+        self._last_steps = burn_in + iters
+        if sync:
+            self.synchronize()
+
+    def trace(self):
+        out = np.zeros((self.n_chains, self._last_steps), np.uint8)
+        self._ck(self.L.mcmc_chains_get_trace(self.h, _ptr(out, np.uint8)))
+        return out
+
+    def labels(self, which=0, canonical=True):
+        out = np.zeros((self.n_chains, self.s_max), np.uint16)
+        self._ck(self.L.mcmc_chains_get_labels(self.h, which, int(canonical), _ptr(out, np.uint16)))
+        return out
+
+    def scalars(self):
+        n = self.n_chains
+        d = dict(energy=np.zeros(n), best_energy=np.zeros(n), state_hash=np.zeros(n, np.uint64),
+                 trace_hash=np.zeros(n, np.uint64), n_accept=np.zeros(n, np.uint64),
+                 n_case=np.zeros((n, 3), np.uint64), status=np.zeros(n, np.int32),
+                 top_count=np.zeros(n, np.uint64), top_hash=np.zeros(n, np.uint64),
+                 overflow=np.zeros(n, np.uint64))
+        self._ck(self.L.mcmc_chains_get_scalars(self.h, *[v.ctypes.data_as(C.c_void_p) for v in d.values()]))
+        return d
+
+    def visits(self):
+        cap = self.p.visit_capacity
+        hh = np.zeros((self.n_chains, cap), np.uint64); cc = np.zeros((self.n_chains, cap), np.uint64)
+        self._ck(self.L.mcmc_chains_get_visits(self.h, _ptr(hh, np.uint64), _ptr(cc, np.uint64)))
+        return [{int(h): int(c) for h, c in zip(hh[k], cc[k]) if c} for k in range(self.n_chains)]
+
+    def marginals(self, frame):
+        out = np.zeros((self.s_max, self.p.marginal_bins), np.uint64)
+        self._ck(self.L.mcmc_frame_get_marginals(self.h, frame, _ptr(out, np.uint64)))
+        return out
+
+    def recompute_energy(self):
+        out = np.zeros(self.n_chains)
+        self._ck(self.L.mcmc_chains_recompute_energy(self.h, _ptr(out, np.float64)))
+        return out
+
+    # ---- plumbing / measurement
+    def set_stream(self, hip_stream_handle):
+        self._ck(self.L.mcmc_ctx_set_stream(self.h, C.c_void_p(hip_stream_handle)))
+
+    def synchronize(self):
+        self._ck(self.L.mcmc_ctx_synchronize(self.h))
+
+    def set_timing(self, on=True):
+        self._ck(self.L.mcmc_set_timing(self.h, int(on)))
+
+    def last_kernel_ms(self, kernel):
+        return float(self.L.mcmc_last_kernel_ms(self.h, kernel))
+
+    def selftest_math(self, x, y):
+        x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+        ol = np.zeros_like(x); oe = np.zeros_like(x); od = np.zeros_like(x)
+        self._ck(self.L.mcmc_selftest_math(self.h, _ptr(x, np.float64), _ptr(y, np.float64), x.size,
+                                           _ptr(ol, np.float64), _ptr(oe, np.float64), _ptr(od, np.float64)))
+        return ol, oe, od
+
+    def selftest_philox(self, ctr, key):
+        ctr = np.ascontiguousarray(ctr, np.uint32); key = np.ascontiguousarray(key, np.uint32)
+        out = np.zeros(4, np.uint32)
+        self._ck(self.L.mcmc_selftest_philox(self.h, _ptr(ctr, np.uint32), _ptr(key, np.uint32),
+                                             _ptr(out, np.uint32)))
+        return out
+
+
+def load_scene(ctx: Context, frame: int, scene):
+    """Upload one mcmc_amd.scene.Scene and its adjacency into `frame`."""
+    ctx.frame_upload(frame, scene.disp, scene.label, scene.n_superpixels)
+    ctx.frame_set_graph(frame, scene.row_ptr, scene.col)

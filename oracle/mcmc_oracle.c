@@ -1,0 +1,838 @@
+/*
+ * mcmc_oracle.c -- ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, double precision, no FMA contraction) of the
+ * Path-A hot path of a-price/MCMC: superpixel moments, local plane fit, fused
+ * segment fit + log-energy, edge probabilities, Swendsen-Wang component growth,
+ * target selection, Metropolis-Hastings accept, state hash and visit statistics.
+ *
+ * Nothing under mcmc_amd/ may include, link or call this file.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+ * checker ("port" baseline), never as the thing shipped.
+ *
+ * PARITY PINNING: the reference (/root/reference) holds NO golden vectors, no
+ * known-answer tests and no seeded runs for this path,
+ * and it cannot be compiled here (gtsam/Eigen/OpenCV absent).  Its arithmetic
+ * lives in gtsam 2.x (un-vendored, un-pinned).  This restatement is therefore
+ * pinned by (1) tests/literal_ref.py, a numpy emulation of the gtsam call
+ * sequence (whitened QR per superpixel -> stacked QR -> factor errors ->
+ * covariance determinant) checked to 1e-9 relative, (2) Random123's published
+ * Philox4x32-10 known-answer vectors, (3) libm log/exp for det_log/det_exp.
+ * Where none of those reach (sampler trajectories) it is "parity unpinned":
+ * the reference seeds libc rand() from time(NULL) and iterates containers in
+ * heap-pointer order, so it has no reproducible trajectory to match.
+ *
+ * Every function cites the reference file:line it follows.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_NLANE 64
+#define ORC_NOLABEL 0xFFFFu
+#define ORC_FIT_STRIDE 12
+#define ORC_MOM_STRIDE 10
+
+/* status codes shared with include/mcmc_amd.h by value */
+#define ORC_OK 0
+#define ORC_E_BADARG (-1)
+#define ORC_E_NAN_RATIO (-4)
+#define ORC_E_INF_ENERGY (-5)
+
+/* ------------------------------------------------------------------------- */
+/* Philox4x32-10 (Salmon et al., SC'11; Random123 reference constants).       */
+/* The reference draws from libc rand() (can05_sampler.cpp:52); Philox is the */
+/* build's replacement so CPU and GPU can share one counter-based stream.     */
+/* key = (seed, global chain id); counter = (step_lo, step_hi, block, TAG).   */
+/* ------------------------------------------------------------------------- */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+#define PHILOX_TAG 0x4D434D43u /* "MCMC" */
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n1 = lo1;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/*
+ * Draw d of a step (d = 0, 1, 2, ... in the reference's rand() call order)
+ * is word (d>>6)&3 of Philox block (d>>8)*64 + (d&63): a batch of 256 draws
+ * is one Philox block per lane of a 64-wide wavefront.
+ */
+typedef struct {
+    uint32_t key[2];
+    uint32_t step_lo, step_hi;
+    uint32_t ndraw;       /* draws consumed this step */
+    uint32_t cur_batch;   /* batch cached in buf */
+    uint8_t have[64];
+    uint32_t buf[64][4];
+} orc_rng;
+
+static void rng_begin(orc_rng *g, uint32_t seed, uint32_t chain, uint64_t step)
+{
+    g->key[0] = seed; g->key[1] = chain;
+    g->step_lo = (uint32_t)step; g->step_hi = (uint32_t)(step >> 32);
+    g->ndraw = 0; g->cur_batch = 0xFFFFFFFFu;
+}
+
+static uint32_t rng_u32(orc_rng *g)
+{
+    uint32_t d = g->ndraw++;
+    uint32_t batch = d >> 8, lane = d & 63u, w = (d >> 6) & 3u;
+    if (batch != g->cur_batch) { memset(g->have, 0, sizeof g->have); g->cur_batch = batch; }
+    if (!g->have[lane]) {
+        uint32_t ctr[4] = { g->step_lo, g->step_hi, batch * 64u + lane, PHILOX_TAG };
+        orc_philox4x32_10(ctr, g->key, g->buf[lane]);
+        g->have[lane] = 1;
+    }
+    return g->buf[lane][w];
+}
+
+/* rand()/RAND_MAX is inclusive of 1.0 (MCMC.h:223, Segmentation.cpp:23,109). */
+static double rng_unif(orc_rng *g)
+{
+    return (double)rng_u32(g) / 4294967295.0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Deterministic log / exp from IEEE + - * / and bit moves only, so that the  */
+/* CPU and the GPU produce the same bits (libm and OCML differ in the last    */
+/* ulp).  Accuracy ~2 ulp; checked against libm in tests.                     */
+/* ------------------------------------------------------------------------- */
+static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+
+#define DET_LN2_HI 6.93147180369123816490e-01 /* fdlibm split of ln 2 */
+#define DET_LN2_LO 1.90821492927058770002e-10
+#define DET_INV_LN2 1.44269504088896338700e+00
+#define DET_SQRT2 1.41421356237309514547e+00
+
+double orc_det_log(double x)
+{
+    if (x != x) return x;
+    if (x < 0.0) return u2d(0x7FF8000000000000ull);
+    if (x == 0.0) return u2d(0xFFF0000000000000ull);
+    uint64_t u = d2u(x);
+    if (u == 0x7FF0000000000000ull) return x;
+    int e = 0;
+    if ((u >> 52) == 0) { /* subnormal: scale by 2^54 (exact) */
+        x = x * 18014398509481984.0;
+        u = d2u(x);
+        e = -54;
+    }
+    e += (int)(u >> 52) - 1023;
+    double m = u2d((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > DET_SQRT2) { m = m * 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    /* atanh series: log(m) = 2s (1 + z/3 + z^2/5 + ... + z^11/23) */
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    double lm = 2.0 * s + (2.0 * s) * (z * p);
+    double de = (double)e;
+    return de * DET_LN2_HI + (lm + de * DET_LN2_LO);
+}
+
+double orc_det_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.782712893384) return u2d(0x7FF0000000000000ull);
+    if (x < -745.2) return 0.0;
+    double t = x * DET_INV_LN2;
+    long long k = (long long)(t + (t < 0.0 ? -0.5 : 0.5)); /* round half away */
+    double dk = (double)k;
+    double r = (x - dk * DET_LN2_HI) - dk * DET_LN2_LO;
+    /* Taylor to r^13, Horner; |r| <= 0.347 */
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    /* scale by 2^k in two exact steps so subnormal results round once */
+    long long k1 = k / 2, k2 = k - k1;
+    double s1 = u2d((uint64_t)(k1 + 1023) << 52);
+    double s2 = u2d((uint64_t)(k2 + 1023) << 52);
+    return (p * s1) * s2;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Wave-order reductions.  The only order-sensitive f64 reductions on the     */
+/* path are mirrored between CPU and GPU as: 64 lane partials, then an xor    */
+/* butterfly with offsets 1,2,4,8,16,32.  (The reference's order is the heap  */
+/* address order of std::set/std::map, i.e. arbitrary.)                        */
+/* ------------------------------------------------------------------------- */
+static double wave_sum(const double *p)
+{
+    double a[ORC_NLANE], b[ORC_NLANE];
+    memcpy(a, p, sizeof a);
+    for (int off = 1; off < ORC_NLANE; off <<= 1) {
+        for (int l = 0; l < ORC_NLANE; ++l) b[l] = a[l] + a[l ^ off];
+        memcpy(a, b, sizeof a);
+    }
+    return a[0];
+}
+
+static double wave_prod(const double *p)
+{
+    double a[ORC_NLANE], b[ORC_NLANE];
+    memcpy(a, p, sizeof a);
+    for (int off = 1; off < ORC_NLANE; off <<= 1) {
+        for (int l = 0; l < ORC_NLANE; ++l) b[l] = a[l] * a[l ^ off];
+        memcpy(a, b, sizeof a);
+    }
+    return a[0];
+}
+
+/* ------------------------------------------------------------------------- */
+/* A1/A2: moments.  createSuperPixels fills A_ rows [u v 1] and b_ with the   */
+/* short disparity (OverSegmentation.cpp:145-162); solve() forms the weighted */
+/* normal equations (MyMath.h:120-154).  Sufficient statistics, exact int64:  */
+/*   N, Su, Sv, Suu, Suv, Svv, Sb, Sub, Svb, Sbb.                              */
+/* ------------------------------------------------------------------------- */
+int orc_moments(const int16_t *disp, const uint16_t *label, int W, int H, int S, int64_t *mom)
+{
+    memset(mom, 0, sizeof(int64_t) * (size_t)S * ORC_MOM_STRIDE);
+    for (int v = 0; v < H; ++v) {
+        for (int u = 0; u < W; ++u) {
+            size_t k = (size_t)v * W + u;
+            unsigned s = label[k];
+            if (s >= (unsigned)S) continue;
+            int64_t b = disp[k];
+            int64_t *m = mom + (size_t)s * ORC_MOM_STRIDE;
+            m[0] += 1; m[1] += u; m[2] += v;
+            m[3] += (int64_t)u * u; m[4] += (int64_t)u * v; m[5] += (int64_t)v * v;
+            m[6] += b; m[7] += u * b; m[8] += v * b; m[9] += b * b;
+        }
+    }
+    return ORC_OK;
+}
+
+/* 3x3 SPD solve by LDL^T without pivoting, fixed evaluation order.  Stands   */
+/* in for gtsam's QR elimination (MyMath.h:141-143, 238-240); same solution   */
+/* of the same normal equations.  Returns pivots in d[3].                      */
+static void ldl3(const double a[6] /* a11 a12 a22 a13 a23 a33 */, const double r[3],
+                 double x[3], double d[3])
+{
+    double a11 = a[0], a12 = a[1], a22 = a[2], a13 = a[3], a23 = a[4], a33 = a[5];
+    double d1 = a11;
+    double l21 = a12 / d1;
+    double l31 = a13 / d1;
+    double d2 = a22 - l21 * a12;
+    double t32 = a23 - l31 * a12;
+    double l32 = t32 / d2;
+    double d3 = (a33 - l31 * a13) - l32 * t32;
+    double y1 = r[0];
+    double y2 = r[1] - l21 * y1;
+    double y3 = (r[2] - l31 * y1) - l32 * y2;
+    double z1 = y1 / d1, z2 = y2 / d2, z3 = y3 / d3;
+    double x3 = z3;
+    double x2 = z2 - l32 * x3;
+    double x1 = (z1 - l21 * x2) - l31 * x3;
+    x[0] = x1; x[1] = x2; x[2] = x3;
+    d[0] = d1; d[1] = d2; d[2] = d3;
+}
+
+/*
+ * A2 local fit (MyMath.h:120-170) + A1 filter (OverSegmentation.cpp:198-222,
+ * 422-455).  Coordinates are shifted to the frame centre (cx=W/2, cy=H/2) in
+ * exact integer arithmetic before going to double: energies are invariant
+ * under the shift (unimodular change of basis), conditioning improves ~1e5x.
+ * fit record (12 doubles): Suu Suv Svv Su Sv N | Sub Svb Sb | theta_a theta_b theta_c
+ * theta is in centred coordinates: disparity = a*(u-cx) + b*(v-cy) + c.
+ * local_err = 1/2 |A theta - b|^2 / var (MyMath.h:146-150), informational.
+ */
+int orc_local_fit(const int64_t *mom, int W, int H, int S, double var,
+                  double *fit, uint8_t *valid, double *local_err)
+{
+    int64_t cx = W / 2, cy = H / 2;
+    for (int s = 0; s < S; ++s) {
+        const int64_t *m = mom + (size_t)s * ORC_MOM_STRIDE;
+        double *f = fit + (size_t)s * ORC_FIT_STRIDE;
+        int64_t n = m[0];
+        int64_t su = m[1] - cx * n, sv = m[2] - cy * n;
+        int64_t suu = m[3] - 2 * cx * m[1] + cx * cx * n;
+        int64_t suv = m[4] - cx * m[2] - cy * m[1] + cx * cy * n;
+        int64_t svv = m[5] - 2 * cy * m[2] + cy * cy * n;
+        int64_t sb = m[6];
+        int64_t sub = m[7] - cx * m[6];
+        int64_t svb = m[8] - cy * m[6];
+        /* isLinear: all u equal or all v equal <=> N*Suu == Su^2 (integers) */
+        __int128 du = (__int128)n * suu - (__int128)su * su;
+        __int128 dv = (__int128)n * svv - (__int128)sv * sv;
+        int ok = (n >= 10) && (du != 0) && (dv != 0) && (sb != 0);
+        valid[s] = (uint8_t)ok;
+        f[0] = (double)suu; f[1] = (double)suv; f[2] = (double)svv;
+        f[3] = (double)su;  f[4] = (double)sv;  f[5] = (double)n;
+        f[6] = (double)sub; f[7] = (double)svb; f[8] = (double)sb;
+        if (ok) {
+            double a[6] = { f[0], f[1], f[2], f[3], f[4], f[5] };
+            double r[3] = { f[6], f[7], f[8] };
+            double x[3], d[3];
+            ldl3(a, r, x, d);
+            f[9] = x[0]; f[10] = x[1]; f[11] = x[2];
+            if (local_err) {
+                double sse = (double)m[9] - ((x[0] * r[0] + x[1] * r[1]) + x[2] * r[2]);
+                local_err[s] = sse / (2.0 * var);
+            }
+        } else {
+            f[9] = f[10] = f[11] = 0.0;
+            if (local_err) local_err[s] = 0.0;
+        }
+    }
+    return ORC_OK;
+}
+
+#define LOG_2PI 1.8378770664093453
+
+/*
+ * A3/A4: fit() (MyMath.h:189-275) + Segment::fitGlobalSurface/computeProbability
+ * (Graph.cpp:69-138).  mem[i]==which selects the members.  Information-form
+ * fusion: M = sum M_i, m = sum m_i (exact: integer-valued doubles),
+ * theta = M^-1 m; totalError = sum_i 1/2 (theta-theta_i)' M_i (theta-theta_i)/var
+ * (the factor errors of MyMath.h:247-252; local error_ is NOT added,
+ * Graph.cpp:101); probabilityL = -error + log sqrt det(2 pi Lambda^-1).
+ * Quirk kept: NaN -> 0.75 (Graph.cpp:134); +-inf -> status (Graph.cpp:137).
+ */
+typedef struct {
+    double probL, err, theta[3], logdet;
+    int n, minid, status;
+} orc_segfit;
+
+static void seg_eval(const double *fit, int S, const uint8_t *mem, uint8_t which,
+                     double var, double log_var, orc_segfit *out)
+{
+    double a[6] = { 0, 0, 0, 0, 0, 0 }, r[3] = { 0, 0, 0 };
+    int n = 0, minid = -1;
+    for (int i = 0; i < S; ++i) {
+        if (mem[i] != which) continue;
+        const double *f = fit + (size_t)i * ORC_FIT_STRIDE;
+        a[0] += f[0]; a[1] += f[1]; a[2] += f[2]; a[3] += f[3]; a[4] += f[4]; a[5] += f[5];
+        r[0] += f[6]; r[1] += f[7]; r[2] += f[8];
+        if (minid < 0) minid = i;
+        n++;
+    }
+    out->n = n; out->minid = minid; out->status = ORC_OK;
+    if (n == 0) { out->probL = 0.0; out->err = 0.0; out->logdet = 0.0;
+                  out->theta[0] = out->theta[1] = out->theta[2] = 0.0; return; }
+    double x[3], d[3];
+    ldl3(a, r, x, d);
+    double part[ORC_NLANE];
+    for (int l = 0; l < ORC_NLANE; ++l) part[l] = 0.0;
+    for (int i = 0; i < S; ++i) {
+        if (mem[i] != which) continue;
+        const double *f = fit + (size_t)i * ORC_FIT_STRIDE;
+        double da = x[0] - f[9], db = x[1] - f[10], dc = x[2] - f[11];
+        double e = da * ((f[0] * da + f[1] * db) + f[3] * dc)
+                 + db * ((f[1] * da + f[2] * db) + f[4] * dc)
+                 + dc * ((f[3] * da + f[4] * db) + f[5] * dc);
+        part[i & (ORC_NLANE - 1)] += e;
+    }
+    double err = wave_sum(part) / (2.0 * var);
+    double logdet = ((orc_det_log(d[0]) + orc_det_log(d[1])) + orc_det_log(d[2])) - 3.0 * log_var;
+    double p = -err + 0.5 * (3.0 * LOG_2PI - logdet);
+    if (p != p) p = 0.75;
+    if (p - p != 0.0) out->status = ORC_E_INF_ENERGY;
+    out->probL = p; out->err = err; out->logdet = logdet;
+    out->theta[0] = x[0]; out->theta[1] = x[1]; out->theta[2] = x[2];
+}
+
+/* public wrapper: members given as an id list */
+int orc_segment_probability(const double *fit, int S, const uint32_t *members, int n, double var,
+                            double *probL, double *theta3, double *err)
+{
+    uint8_t *mem = (uint8_t *)calloc((size_t)S, 1);
+    for (int k = 0; k < n; ++k) {
+        if (members[k] >= (uint32_t)S) { free(mem); return ORC_E_BADARG; }
+        mem[members[k]] = 1;
+    }
+    orc_segfit r;
+    seg_eval(fit, S, mem, 1, var, orc_det_log(var), &r);
+    free(mem);
+    if (probL) *probL = r.probL;
+    if (err) *err = r.err;
+    if (theta3) { theta3[0] = r.theta[0]; theta3[1] = r.theta[1]; theta3[2] = r.theta[2]; }
+    return r.status;
+}
+
+/*
+ * A11: Problem::computeEdgeProbability (Problem.cpp:420-445) with
+ * createSegmentations (:372-418) and addLogProbs (MyMath.h:284-296).
+ * q = exp(T - logaddexp(T, Sep)); T = probL({i,j}), Sep = probL({i})+probL({j}).
+ * An edge with an endpoint that failed the A1 filter does not exist in the
+ * reference's neighbor maps (OverSegmentation.cpp:205-214): marked q = -1.
+ */
+int orc_edge_probs(const double *fit, const uint8_t *valid, int S, const uint32_t *row_ptr,
+                   const uint32_t *col, double var, double *q)
+{
+    double log_var = orc_det_log(var);
+    uint8_t *mem = (uint8_t *)calloc((size_t)S, 1);
+    int status = ORC_OK;
+    for (int i = 0; i < S; ++i) {
+        for (uint32_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+            uint32_t j = col[e];
+            if (j >= (uint32_t)S || (int)j == i || !valid[i] || !valid[j]) { q[e] = -1.0; continue; }
+            orc_segfit t, si, sj;
+            mem[i] = 1; mem[j] = 1;
+            seg_eval(fit, S, mem, 1, var, log_var, &t);
+            mem[j] = 0;
+            seg_eval(fit, S, mem, 1, var, log_var, &si);
+            mem[i] = 0; mem[j] = 1;
+            seg_eval(fit, S, mem, 1, var, log_var, &sj);
+            mem[j] = 0;
+            double T = t.probL;
+            double Sp = si.probL + sj.probL; /* Segmentation::computeProbability, Segmentation.cpp:185-195 */
+            double lB, lS;
+            if (T > Sp) { lB = T; lS = Sp; } else { lS = T; lB = Sp; }
+            double sum = lB + orc_det_log(1.0 + orc_det_exp(lS - lB));
+            double ratio = orc_det_exp(T - sum);
+            if (ratio != ratio) status = ORC_E_NAN_RATIO; /* Problem.cpp:443 */
+            q[e] = ratio;
+        }
+    }
+    free(mem);
+    return status;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Sampler state.  Canonical order (the reference's is heap-pointer order):   */
+/* superpixels by id; a segment is named by its smallest member id, so the    */
+/* label array itself is canonical and "set order" of segments is ascending   */
+/* label.                                                                      */
+/* ------------------------------------------------------------------------- */
+static inline uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+typedef struct {
+    uint64_t hash;
+    uint64_t count;
+} orc_visit;
+
+typedef struct orc_chains {
+    /* frame (borrowed) */
+    int S, Sv;
+    const double *fit; const uint8_t *valid;
+    const uint32_t *row_ptr, *col; const double *q;
+    uint32_t *vlist;
+    double var, log_var, new_seg_prob;
+    /* chains */
+    int n_chains; uint32_t seed, chain_offset;
+    uint64_t step;       /* steps already taken by every chain */
+    uint16_t *label;     /* n_chains*S, min-id labels */
+    double *segP;        /* n_chains*S, probabilityL_ by root label */
+    uint32_t *segN;      /* n_chains*S, sizes by root label */
+    double *energy;      /* running sum of probabilityL_ (Segmentation::computeProbability) */
+    double *best_energy; uint16_t *best_label;
+    uint64_t *state_hash, *trace_hash;
+    uint64_t *n_accept, *n_case; /* n_case: 3 per chain */
+    int *status;
+    /* Statistics (Statistics.h:33-47): visit counts keyed by state hash */
+    int hcap; orc_visit *visits; int *n_visits; uint64_t *overflow;
+    uint64_t *top_count; uint64_t *top_hash; uint16_t *top_label;
+    /* marginals of first-appearance labels, summed over chains */
+    int lmax; uint64_t *marg; /* S*lmax */
+    /* scratch */
+    uint8_t *inC, *mem, *nbr; uint32_t *queue;
+} orc_chains;
+
+static uint64_t state_hash_of(const uint16_t *label, const uint8_t *valid, int S)
+{
+    uint64_t h = 0;
+    for (int i = 0; i < S; ++i)
+        if (valid[i]) h += mix64(((uint64_t)i << 32) | label[i]);
+    return h;
+}
+
+/* Segmentation::computeHash's first-appearance relabel (Segmentation.cpp:197-233):
+ * rank of each root among roots, in id order.  Invalid superpixels -> 0xFFFF. */
+static void canonical_labels(const uint16_t *label, const uint8_t *valid, int S, uint16_t *out)
+{
+    uint16_t *rank = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)S);
+    uint16_t r = 0;
+    for (int i = 0; i < S; ++i) rank[i] = (valid[i] && label[i] == i) ? r++ : 0;
+    for (int i = 0; i < S; ++i) out[i] = valid[i] ? rank[label[i]] : (uint16_t)ORC_NOLABEL;
+    free(rank);
+}
+
+void orc_chains_free(orc_chains *c)
+{
+    if (!c) return;
+    free(c->vlist); free(c->label); free(c->segP); free(c->segN); free(c->energy);
+    free(c->best_energy); free(c->best_label); free(c->state_hash); free(c->trace_hash);
+    free(c->n_accept); free(c->n_case); free(c->status); free(c->visits); free(c->n_visits);
+    free(c->overflow); free(c->top_count); free(c->top_hash); free(c->top_label); free(c->marg);
+    free(c->inC); free(c->mem); free(c->nbr); free(c->queue);
+    free(c);
+}
+
+/* Problem::initializeState (Problem.cpp:447-473): every superpixel in ONE segment. */
+orc_chains *orc_chains_create(int S, const double *fit, const uint8_t *valid,
+                              const uint32_t *row_ptr, const uint32_t *col, const double *q,
+                              double var, double new_seg_prob, int n_chains, uint32_t seed,
+                              uint32_t chain_offset, int hcap, int lmax)
+{
+    orc_chains *c = (orc_chains *)calloc(1, sizeof *c);
+    c->S = S; c->fit = fit; c->valid = valid; c->row_ptr = row_ptr; c->col = col; c->q = q;
+    c->var = var; c->log_var = orc_det_log(var); c->new_seg_prob = new_seg_prob;
+    c->n_chains = n_chains; c->seed = seed; c->chain_offset = chain_offset;
+    c->hcap = hcap; c->lmax = lmax;
+    c->vlist = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(S > 0 ? S : 1));
+    for (int i = 0; i < S; ++i) if (valid[i]) c->vlist[c->Sv++] = (uint32_t)i;
+    size_t NS = (size_t)n_chains * (size_t)S;
+    c->label = (uint16_t *)malloc(sizeof(uint16_t) * NS);
+    c->segP = (double *)calloc(NS, sizeof(double));
+    c->segN = (uint32_t *)calloc(NS, sizeof(uint32_t));
+    c->energy = (double *)calloc((size_t)n_chains, sizeof(double));
+    c->best_energy = (double *)calloc((size_t)n_chains, sizeof(double));
+    c->best_label = (uint16_t *)malloc(sizeof(uint16_t) * NS);
+    c->state_hash = (uint64_t *)calloc((size_t)n_chains, 8);
+    c->trace_hash = (uint64_t *)calloc((size_t)n_chains, 8);
+    c->n_accept = (uint64_t *)calloc((size_t)n_chains, 8);
+    c->n_case = (uint64_t *)calloc((size_t)n_chains * 3, 8);
+    c->status = (int *)calloc((size_t)n_chains, sizeof(int));
+    c->visits = (orc_visit *)calloc((size_t)n_chains * (size_t)hcap, sizeof(orc_visit));
+    c->n_visits = (int *)calloc((size_t)n_chains, sizeof(int));
+    c->overflow = (uint64_t *)calloc((size_t)n_chains, 8);
+    c->top_count = (uint64_t *)calloc((size_t)n_chains, 8);
+    c->top_hash = (uint64_t *)calloc((size_t)n_chains, 8);
+    c->top_label = (uint16_t *)malloc(sizeof(uint16_t) * NS);
+    c->marg = (uint64_t *)calloc((size_t)S * (size_t)lmax, 8);
+    c->inC = (uint8_t *)calloc((size_t)S, 1);
+    c->mem = (uint8_t *)calloc((size_t)S, 1);
+    c->nbr = (uint8_t *)calloc((size_t)S, 1);
+    c->queue = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(S > 0 ? S : 1));
+
+    /* one segment holding every valid superpixel, named by the smallest id */
+    uint16_t root = c->Sv ? (uint16_t)c->vlist[0] : 0;
+    for (int i = 0; i < S; ++i) { c->mem[i] = valid[i] ? 1 : 0; }
+    orc_segfit f0;
+    seg_eval(fit, S, c->mem, 1, var, c->log_var, &f0);
+    memset(c->mem, 0, (size_t)S);
+    for (int k = 0; k < n_chains; ++k) {
+        uint16_t *lab = c->label + (size_t)k * S;
+        for (int i = 0; i < S; ++i) lab[i] = valid[i] ? root : (uint16_t)ORC_NOLABEL;
+        if (c->Sv) {
+            c->segP[(size_t)k * S + root] = f0.probL;
+            c->segN[(size_t)k * S + root] = (uint32_t)c->Sv;
+        }
+        c->energy[k] = f0.probL;
+        c->best_energy[k] = f0.probL;
+        memcpy(c->best_label + (size_t)k * S, lab, sizeof(uint16_t) * (size_t)S);
+        memcpy(c->top_label + (size_t)k * S, lab, sizeof(uint16_t) * (size_t)S);
+        c->state_hash[k] = state_hash_of(lab, valid, S);
+        c->status[k] = f0.status;
+    }
+    return c;
+}
+
+/* Statistics::update (Statistics.h:33-47), bounded to hcap distinct states. */
+static void visit_update(orc_chains *c, int k)
+{
+    orc_visit *tab = c->visits + (size_t)k * c->hcap;
+    uint64_t h = c->state_hash[k];
+    int n = c->n_visits[k];
+    uint64_t cnt = 0;
+    int found = 0;
+    for (int i = 0; i < n; ++i)
+        if (tab[i].hash == h) { cnt = ++tab[i].count; found = 1; break; }
+    if (!found) {
+        if (n < c->hcap) { tab[n].hash = h; tab[n].count = 1; c->n_visits[k] = n + 1; cnt = 1; }
+        else { c->overflow[k]++; return; }
+    }
+    /* "best" = most visited (can05_sampler.cpp:36); tie -> smaller hash */
+    if (cnt > c->top_count[k] || (cnt == c->top_count[k] && h < c->top_hash[k])) {
+        if (h != c->top_hash[k] || c->top_count[k] == 0)
+            memcpy(c->top_label + (size_t)k * c->S, c->label + (size_t)k * c->S,
+                   sizeof(uint16_t) * (size_t)c->S);
+        c->top_count[k] = cnt; c->top_hash[k] = h;
+    }
+}
+
+static void marg_update(orc_chains *c, int k)
+{
+    int S = c->S;
+    uint16_t *canon = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)S);
+    canonical_labels(c->label + (size_t)k * S, c->valid, S, canon);
+    for (int i = 0; i < S; ++i) {
+        if (!c->valid[i]) continue;
+        int b = canon[i] < c->lmax ? canon[i] : c->lmax - 1;
+        c->marg[(size_t)i * c->lmax + b]++;
+    }
+    free(canon);
+}
+
+/*
+ * One sampler step for chain k at global step t:
+ * FastMetropolisHastings::iterate (MCMC.h:207-238) -> Problem::propose
+ * (Problem.cpp:116-224) -> Segmentation::createComponent / selectSegment
+ * (Segmentation.cpp:59-149, 10-57) -> Segment ctor fits -> jumpProbability
+ * (Problem.cpp:475-487) -> jump (Problem.cpp:32-74).
+ * Returns trace byte: bit0 accept, bits1-2 case (0=A back to own segment,
+ * 1=B split, 2=C merge/exchange).
+ */
+static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
+{
+    const int S = c->S;
+    uint16_t *lab = c->label + (size_t)k * S;
+    double *segP = c->segP + (size_t)k * S;
+    uint32_t *segN = c->segN + (size_t)k * S;
+    orc_rng g;
+    rng_begin(&g, c->seed, c->chain_offset + (uint32_t)k, t);
+
+    /* pickSuperPixel (Segmentation.cpp:151-183): rand()%S then one unused draw */
+    uint32_t start = c->vlist[rng_u32(&g) % (uint32_t)c->Sv];
+    (void)rng_u32(&g);
+    const uint16_t orig = lab[start];
+
+    /* createComponent BFS (Segmentation.cpp:74-120) */
+    uint32_t qn = 0;
+    c->queue[qn++] = start; c->inC[start] = 1;
+    for (uint32_t head = 0; head < qn; ++head) {
+        uint32_t i = c->queue[head];
+        for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e) {
+            double qe = c->q[e];
+            if (qe < 0.0) continue;               /* not an edge in the reference graph */
+            uint32_t j = c->col[e];
+            if (c->inC[j]) continue;              /* :94 already in component */
+            if (lab[j] != orig) { c->nbr[lab[j]] = 1; continue; } /* :100-105 */
+            double r = rng_unif(&g);              /* :109 */
+            if (r < qe) { c->inC[j] = 1; c->queue[qn++] = j; } /* :110-117, strict */
+        }
+    }
+    const uint32_t csize = qn;
+    const int same = (csize == segN[orig]);      /* Segmentation.cpp:19 */
+
+    /* selectSegment (Segmentation.cpp:10-57) */
+    double u1 = rng_unif(&g);                    /* :23 */
+    int kase; uint16_t next = orig; double ratio;
+    uint32_t nn = 0;
+    for (int i = 0; i < S; ++i) nn += c->nbr[i];
+    if (!same && u1 < c->new_seg_prob) {         /* :25 */
+        kase = 1; ratio = c->new_seg_prob;       /* :28-29 */
+    } else {
+        double existing = same ? 1.0 : (1.0 - c->new_seg_prob); /* :36 */
+        uint32_t numSeg = nn + 1;                /* :39 */
+        uint32_t idx = rng_u32(&g) % numSeg;     /* :40 */
+        if (idx == numSeg - 1) { next = orig; kase = 0; } /* :43-45 */
+        else {
+            uint32_t seen = 0; kase = 2;
+            for (int i = 0; i < S; ++i)
+                if (c->nbr[i]) { if (seen == idx) { next = (uint16_t)i; break; } seen++; }
+        }
+        ratio = existing / (double)numSeg;       /* :55 */
+    }
+
+    double targetL, prop;
+    orc_segfit fB1, fB2;
+    fB1.n = 0; fB1.probL = 0.0; fB1.minid = -1; fB1.status = 0;
+    fB2.n = 0; fB2.probL = 0.0; fB2.minid = -1; fB2.status = 0;
+    int st = ORC_OK;
+    if (kase == 0) {
+        /* Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic, it is used as a log) */
+        prop = ratio; targetL = 1.0;
+    } else {
+        /* separation / merge products (Segmentation.cpp:127-146, Graph.cpp:10-33),
+         * wave order over the BFS queue */
+        double psep[ORC_NLANE], pmrg[ORC_NLANE];
+        for (int l = 0; l < ORC_NLANE; ++l) { psep[l] = 1.0; pmrg[l] = 1.0; }
+        for (uint32_t h = 0; h < qn; ++h) {
+            uint32_t i = c->queue[h];
+            int l = (int)(h & (ORC_NLANE - 1));
+            for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e) {
+                double qe = c->q[e];
+                if (qe < 0.0) continue;
+                uint32_t j = c->col[e];
+                if (lab[j] == orig) { if (!c->inC[j]) psep[l] = psep[l] * (1.0 - qe); }
+                else if (kase == 2 && lab[j] == next) pmrg[l] = pmrg[l] * (1.0 - qe);
+            }
+        }
+        double sep = wave_prod(psep);
+        for (int i = 0; i < S; ++i) {
+            uint8_t m = 0;
+            if (kase == 1) m = c->inC[i] ? 2 : (lab[i] == orig ? 1 : 0);
+            else m = (c->inC[i] || lab[i] == next) ? 2 : ((lab[i] == orig && !same) ? 1 : 0);
+            c->mem[i] = c->valid[i] ? m : 0;
+        }
+        seg_eval(c->fit, S, c->mem, 2, c->var, c->log_var, &fB2);
+        if (!(kase == 2 && same)) seg_eval(c->fit, S, c->mem, 1, c->var, c->log_var, &fB1);
+        if (kase == 1) {
+            prop = ratio * (1.0 / sep);          /* Problem.cpp:188 */
+        } else {
+            double mrg = wave_prod(pmrg);
+            prop = ratio * (mrg / sep);          /* Problem.cpp:206 */
+        }
+        /* jumpProbability (Problem.cpp:475-487) */
+        double sB2_sA1 = fB2.probL - segP[orig];
+        double sB1_sA2 = ((kase == 2 && same) ? 0.0 : fB1.probL) - (kase == 2 ? segP[next] : 0.0);
+        targetL = sB2_sA1 + sB1_sA2;
+        if (fB1.status) st = fB1.status;
+        if (fB2.status) st = fB2.status;
+        if (targetL != targetL || prop != prop) st = ORC_E_NAN_RATIO; /* Problem.cpp:216-217 */
+    }
+
+    /* FastMetropolisHastings::iterate (MCMC.h:218-227) */
+    double aL = targetL + orc_det_log(prop);
+    double a = orc_det_exp(aL);
+    double r = rng_unif(&g);                     /* always drawn */
+    int accept = 1;
+    if (aL < 0.0) { if (r > a) accept = 0; }
+    if (st != ORC_OK) { accept = 0; c->status[k] = st; }
+
+    uint16_t newlab = next;
+    if (accept && kase != 0) {
+        /* jump (Problem.cpp:32-74) with min-id naming */
+        uint16_t L2 = (uint16_t)fB2.minid;
+        uint16_t L1 = (uint16_t)(fB1.n ? fB1.minid : 0);
+        for (int i = 0; i < S; ++i) {
+            if (c->mem[i] == 2) lab[i] = L2;
+            else if (c->mem[i] == 1) lab[i] = L1;
+        }
+        segP[L2] = fB2.probL; segN[L2] = (uint32_t)fB2.n;
+        if (fB1.n) { segP[L1] = fB1.probL; segN[L1] = (uint32_t)fB1.n; }
+        c->energy[k] += targetL;
+        c->state_hash[k] = state_hash_of(lab, c->valid, S);
+        if (c->energy[k] > c->best_energy[k]) {
+            c->best_energy[k] = c->energy[k];
+            memcpy(c->best_label + (size_t)k * S, lab, sizeof(uint16_t) * (size_t)S);
+        }
+        newlab = L2;
+    }
+    if (accept) c->n_accept[k]++;
+    c->n_case[(size_t)k * 3 + kase]++;
+
+    /* clear scratch */
+    for (uint32_t h = 0; h < qn; ++h) c->inC[c->queue[h]] = 0;
+    memset(c->nbr, 0, (size_t)S);
+    memset(c->mem, 0, (size_t)S);
+
+    uint8_t tb = (uint8_t)(accept | (kase << 1));
+    uint64_t w = (uint64_t)tb | ((uint64_t)start << 8) | ((uint64_t)csize << 24) | ((uint64_t)newlab << 40);
+    c->trace_hash[k] = mix64(mix64(c->trace_hash[k] ^ w) ^ c->state_hash[k]);
+    return tb;
+}
+
+/*
+ * MCMC<PROBLEM>::run (MCMC.h:43-89): burn_in steps without statistics, then
+ * iters steps each followed by Statistics::update.  trace (optional) receives
+ * one byte per chain per step, chain-major: trace[k*(burn_in+iters) + s].
+ * A chain whose status is non-zero is frozen (the reference would have thrown).
+ */
+int orc_chains_run(orc_chains *c, uint64_t burn_in, uint64_t iters, uint8_t *trace)
+{
+    if (c->Sv == 0) return ORC_E_BADARG;
+    uint64_t total = burn_in + iters;
+    int worst = ORC_OK;
+    for (int k = 0; k < c->n_chains; ++k) {
+        for (uint64_t s = 0; s < total; ++s) {
+            uint8_t tb = 0xFF;
+            if (c->status[k] == ORC_OK) tb = chain_step(c, k, c->step + s);
+            if (trace) trace[(size_t)k * total + s] = tb;
+            if (s >= burn_in && c->status[k] == ORC_OK) { visit_update(c, k); marg_update(c, k); }
+        }
+        if (c->status[k] != ORC_OK) worst = c->status[k];
+    }
+    c->step += total;
+    return worst;
+}
+
+/* getters ------------------------------------------------------------------ */
+int orc_chains_get_labels(const orc_chains *c, int which /*0 cur,1 best-energy,2 most-visited*/,
+                          int canonical, uint16_t *out)
+{
+    const uint16_t *src = which == 0 ? c->label : (which == 1 ? c->best_label : c->top_label);
+    for (int k = 0; k < c->n_chains; ++k) {
+        if (canonical) canonical_labels(src + (size_t)k * c->S, c->valid, c->S, out + (size_t)k * c->S);
+        else memcpy(out + (size_t)k * c->S, src + (size_t)k * c->S, sizeof(uint16_t) * (size_t)c->S);
+    }
+    return ORC_OK;
+}
+void orc_chains_get_scalars(const orc_chains *c, double *energy, double *best_energy,
+                            uint64_t *state_hash, uint64_t *trace_hash, uint64_t *n_accept,
+                            uint64_t *n_case, int *status, uint64_t *top_count, uint64_t *top_hash,
+                            uint64_t *overflow)
+{
+    size_t n = (size_t)c->n_chains;
+    if (energy) memcpy(energy, c->energy, n * 8);
+    if (best_energy) memcpy(best_energy, c->best_energy, n * 8);
+    if (state_hash) memcpy(state_hash, c->state_hash, n * 8);
+    if (trace_hash) memcpy(trace_hash, c->trace_hash, n * 8);
+    if (n_accept) memcpy(n_accept, c->n_accept, n * 8);
+    if (n_case) memcpy(n_case, c->n_case, n * 24);
+    if (status) memcpy(status, c->status, n * sizeof(int));
+    if (top_count) memcpy(top_count, c->top_count, n * 8);
+    if (top_hash) memcpy(top_hash, c->top_hash, n * 8);
+    if (overflow) memcpy(overflow, c->overflow, n * 8);
+}
+/* visits: out_hash/out_count sized n_chains*hcap; n_out per chain */
+void orc_chains_get_visits(const orc_chains *c, uint64_t *out_hash, uint64_t *out_count, int *n_out)
+{
+    for (int k = 0; k < c->n_chains; ++k) {
+        n_out[k] = c->n_visits[k];
+        for (int i = 0; i < c->hcap; ++i) {
+            out_hash[(size_t)k * c->hcap + i] = c->visits[(size_t)k * c->hcap + i].hash;
+            out_count[(size_t)k * c->hcap + i] = c->visits[(size_t)k * c->hcap + i].count;
+        }
+    }
+}
+void orc_chains_get_marginals(const orc_chains *c, uint64_t *out)
+{
+    memcpy(out, c->marg, sizeof(uint64_t) * (size_t)c->S * (size_t)c->lmax);
+}
+/* Segmentation::computeProbability (Segmentation.cpp:185-195) recomputed from
+ * scratch for the current labels (wave order over roots by id). */
+void orc_chains_recompute_energy(const orc_chains *c, double *out)
+{
+    for (int k = 0; k < c->n_chains; ++k) {
+        const uint16_t *lab = c->label + (size_t)k * c->S;
+        double part[ORC_NLANE];
+        for (int l = 0; l < ORC_NLANE; ++l) part[l] = 0.0;
+        for (int i = 0; i < c->S; ++i)
+            if (c->valid[i] && lab[i] == i) part[i & (ORC_NLANE - 1)] += c->segP[(size_t)k * c->S + i];
+        out[k] = wave_sum(part);
+    }
+}
+uint64_t orc_mix64(uint64_t x) { return mix64(x); }
+double orc_wave_sum(const double *p) { return wave_sum(p); }
+double orc_wave_prod(const double *p) { return wave_prod(p); }

@@ -1,0 +1,161 @@
+"""ctypes loader for the CPU oracle (oracle/_build/libmcmc_oracle.so).
+
+Test infrastructure only: the product package (mcmc_amd/) never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "_build", "libmcmc_oracle.so")
+
+_lib = None
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C")
+i16p = np.ctypeslib.ndpointer(np.int16, flags="C")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+
+
+def build():
+    """Compile the oracle with gcc if the .so is missing or stale."""
+    srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
+            if f.endswith(".c")]
+    if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
+        return
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(SO)
+    L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
+    L.orc_det_log.restype = C.c_double; L.orc_det_log.argtypes = [C.c_double]
+    L.orc_det_exp.restype = C.c_double; L.orc_det_exp.argtypes = [C.c_double]
+    L.orc_moments.argtypes = [i16p, u16p, C.c_int, C.c_int, C.c_int, i64p]
+    L.orc_local_fit.argtypes = [i64p, C.c_int, C.c_int, C.c_int, C.c_double, f64p, u8p, f64p]
+    L.orc_segment_probability.argtypes = [f64p, C.c_int, u32p, C.c_int, C.c_double,
+                                          C.POINTER(C.c_double), f64p, C.POINTER(C.c_double)]
+    L.orc_edge_probs.argtypes = [f64p, u8p, C.c_int, u32p, u32p, C.c_double, f64p]
+    L.orc_chains_create.restype = C.c_void_p
+    L.orc_chains_create.argtypes = [C.c_int, f64p, u8p, u32p, u32p, f64p, C.c_double, C.c_double,
+                                    C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    L.orc_chains_free.argtypes = [C.c_void_p]
+    L.orc_chains_run.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.orc_chains_get_labels.argtypes = [C.c_void_p, C.c_int, C.c_int, u16p]
+    L.orc_chains_get_scalars.argtypes = [C.c_void_p] + [C.c_void_p] * 10
+    L.orc_chains_get_visits.argtypes = [C.c_void_p, u64p, u64p, i32p]
+    L.orc_chains_get_marginals.argtypes = [C.c_void_p, u64p]
+    L.orc_chains_recompute_energy.argtypes = [C.c_void_p, f64p]
+    L.orc_mix64.restype = C.c_uint64; L.orc_mix64.argtypes = [C.c_uint64]
+    L.orc_wave_sum.restype = C.c_double; L.orc_wave_sum.argtypes = [f64p]
+    L.orc_wave_prod.restype = C.c_double; L.orc_wave_prod.argtypes = [f64p]
+    _lib = L
+    return L
+
+
+# ---------------------------------------------------------------- convenience
+def moments(disp, label, S):
+    H, W = disp.shape
+    out = np.zeros((S, 10), np.int64)
+    lib().orc_moments(np.ascontiguousarray(disp, np.int16), np.ascontiguousarray(label, np.uint16),
+                      W, H, S, out)
+    return out
+
+
+def local_fit(mom, W, H, var=7.0):
+    S = mom.shape[0]
+    fit = np.zeros((S, 12), np.float64)
+    valid = np.zeros(S, np.uint8)
+    lerr = np.zeros(S, np.float64)
+    lib().orc_local_fit(np.ascontiguousarray(mom), W, H, S, var, fit, valid, lerr)
+    return fit, valid, lerr
+
+
+def segment_probability(fit, members, var=7.0):
+    p = C.c_double(); e = C.c_double()
+    th = np.zeros(3, np.float64)
+    m = np.ascontiguousarray(members, np.uint32)
+    st = lib().orc_segment_probability(np.ascontiguousarray(fit), fit.shape[0], m, m.size, var,
+                                       C.byref(p), th, C.byref(e))
+    return st, p.value, th, e.value
+
+
+def edge_probs(fit, valid, row_ptr, col, var=7.0):
+    q = np.zeros(col.size, np.float64)
+    st = lib().orc_edge_probs(np.ascontiguousarray(fit), np.ascontiguousarray(valid), fit.shape[0],
+                              np.ascontiguousarray(row_ptr, np.uint32),
+                              np.ascontiguousarray(col, np.uint32), var, q)
+    return st, q
+
+
+class Chains:
+    """Oracle sampler over one frame (mirrors mcmc_amd.host.Chains)."""
+
+    def __init__(self, fit, valid, row_ptr, col, q, n_chains, seed, chain_offset=0,
+                 var=7.0, new_seg_prob=0.8, hcap=256, lmax=64):
+        self.S = fit.shape[0]
+        self.n = n_chains
+        self.hcap, self.lmax = hcap, lmax
+        # keep references alive: the oracle borrows these buffers
+        self._keep = [np.ascontiguousarray(fit), np.ascontiguousarray(valid),
+                      np.ascontiguousarray(row_ptr, np.uint32), np.ascontiguousarray(col, np.uint32),
+                      np.ascontiguousarray(q)]
+        self.h = lib().orc_chains_create(self.S, *self._keep, var, new_seg_prob, n_chains, seed,
+                                         chain_offset, hcap, lmax)
+
+    def run(self, burn_in, iters, trace=False):
+        tr = np.zeros((self.n, burn_in + iters), np.uint8) if trace else None
+        st = lib().orc_chains_run(self.h, burn_in, iters,
+                                  tr.ctypes.data_as(C.c_void_p) if trace else None)
+        return st, tr
+
+    def labels(self, which=0, canonical=True):
+        out = np.zeros((self.n, self.S), np.uint16)
+        lib().orc_chains_get_labels(self.h, which, int(canonical), out)
+        return out
+
+    def scalars(self):
+        n = self.n
+        d = dict(energy=np.zeros(n), best_energy=np.zeros(n), state_hash=np.zeros(n, np.uint64),
+                 trace_hash=np.zeros(n, np.uint64), n_accept=np.zeros(n, np.uint64),
+                 n_case=np.zeros((n, 3), np.uint64), status=np.zeros(n, np.int32),
+                 top_count=np.zeros(n, np.uint64), top_hash=np.zeros(n, np.uint64),
+                 overflow=np.zeros(n, np.uint64))
+        lib().orc_chains_get_scalars(self.h, *[v.ctypes.data_as(C.c_void_p) for v in d.values()])
+        return d
+
+    def visits(self):
+        hh = np.zeros((self.n, self.hcap), np.uint64)
+        cc = np.zeros((self.n, self.hcap), np.uint64)
+        nn = np.zeros(self.n, np.int32)
+        lib().orc_chains_get_visits(self.h, hh, cc, nn)
+        return [dict(zip(hh[k, :nn[k]].tolist(), cc[k, :nn[k]].tolist())) for k in range(self.n)]
+
+    def marginals(self):
+        out = np.zeros((self.S, self.lmax), np.uint64)
+        lib().orc_chains_get_marginals(self.h, out)
+        return out
+
+    def recompute_energy(self):
+        out = np.zeros(self.n)
+        lib().orc_chains_recompute_energy(self.h, out)
+        return out
+
+    def __del__(self):
+        try:
+            lib().orc_chains_free(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs and against the committed golden fixtures.
+
+Bar: bit-exact for integer / index / accept-reject work and for every f64 the
+decisions depend on (same IEEE operations in the same order on both sides);
+1e-6 relative against the literal-reference goldens.
+"""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+
+
+def _case(golden, ci):
+    p = f"c{ci}_"
+    return {k[len(p):]: golden[k] for k in golden.files if k.startswith(p)}
+
+
+def _load(ctx, frame, sc):
+    from mcmc_amd import host
+    host.load_scene(ctx, frame, sc)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def test_device_math_bit_exact(gpu_ctx_factory):
+    ctx = gpu_ctx_factory()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(-745, 709, 20000),
+                        rng.uniform(-2, 2, 10000), [0.0, 1.0, 7.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310]])
+    y = np.concatenate([rng.uniform(-1e3, 1e3, x.size - 3), [3.0, 7.0, 4294967295.0]])
+    gl, ge, gd = ctx.selftest_math(x, y)
+    L = O.lib()
+    wl = np.array([L.orc_det_log(float(v)) for v in x]); we = np.array([L.orc_det_exp(float(v)) for v in x])
+    assert np.array_equal(bits(gl), bits(wl))
+    assert np.array_equal(bits(ge), bits(we))
+    with np.errstate(all="ignore"):
+        assert np.array_equal(bits(gd), bits(x / y))   # IEEE division on the device
+    for ctr, key in [([0, 0, 0, 0], [0, 0]), ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])]:
+        want = np.zeros(4, np.uint32)
+        L.orc_philox4x32_10(np.array(ctr, np.uint32), np.array(key, np.uint32), want)
+        assert np.array_equal(ctx.selftest_philox(ctr, key), want)
+    assert ctx.selftest_philox([0, 0, 0, 0], [0, 0]).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_frame_kernels_golden(golden, gpu_ctx_factory, ci):
+    g = _case(golden, ci)
+    S = int(g["S"]); H, W = g["disp"].shape
+    ctx = gpu_ctx_factory(width=W, height=H)
+    ctx.frames_alloc(1, S, g["col"].size)
+    ctx.frame_upload(0, g["disp"], g["label"], S)
+    ctx.frame_set_graph(0, g["row_ptr"], g["col"])
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    assert np.array_equal(ctx.moments(0), g["moments"])
+    fit, valid, lerr = ctx.local_fit(0)
+    th = fit[:, 9:12].copy(); th[:, 2] -= th[:, 0] * (W // 2) + th[:, 1] * (H // 2)
+    assert valid.all() and np.allclose(th, g["theta_raw"], rtol=REL, atol=1e-9)
+    assert np.allclose(lerr, g["local_err"], rtol=REL, atol=1e-9)
+    assert np.allclose(ctx.edge_probs(0), g["q"], rtol=REL, atol=1e-12)
+    sp, si = g["set_ptr"], g["set_idx"]
+    for k in range(len(sp) - 1):
+        p, th3, err = ctx.segment_probability(0, si[sp[k]:sp[k + 1]])
+        assert abs(p - g["set_probL"][k]) <= REL * abs(g["set_probL"][k])
+        assert abs(err - g["set_err"][k]) <= REL * abs(g["set_err"][k]) + 1e-9
+    # and bit-exact against the oracle
+    ofit, ovalid, olerr = O.local_fit(O.moments(g["disp"], g["label"], S), W, H)
+    assert np.array_equal(bits(fit), bits(ofit)) and np.array_equal(valid, ovalid)
+    assert np.array_equal(bits(lerr), bits(olerr))
+    _, oq = O.edge_probs(ofit, ovalid, g["row_ptr"], g["col"])
+    assert np.array_equal(bits(ctx.edge_probs(0)), bits(oq))
+    for k in range(len(sp) - 1):
+        p, th3, err = ctx.segment_probability(0, si[sp[k]:sp[k + 1]])
+        _, op, oth, oerr = O.segment_probability(ofit, si[sp[k]:sp[k + 1]])
+        assert bits(p) == bits(op) and bits(err) == bits(oerr) and np.array_equal(bits(th3), bits(oth))
+
+
+@pytest.mark.parametrize("shape", [(640, 480, 500, 8), (1920, 1080, 4000, 24), (100, 37, 12, 2), (648, 480, 300, 4)])
+def test_moments_full_size_bit_exact(gpu_ctx_factory, shape):
+    # BASELINE configs 2 and 3 at full size; a width that is not a multiple of 8 (generic kernel);
+    # a width (648) for which 8*blockDim is not a multiple of W.
+    from mcmc_amd.scene import make_scene
+    W, H, S, K = shape
+    sc = make_scene(width=W, height=H, n_planes=K, n_superpixels=S, seed=2)
+    ctx = gpu_ctx_factory(width=W, height=H)
+    ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments()
+    want = O.moments(sc.disp, sc.label, sc.n_superpixels)
+    assert np.array_equal(ctx.moments(0), want)
+    # checksum-of-checksums property: totals over superpixels equal totals over labelled pixels
+    m = sc.label < sc.n_superpixels
+    assert ctx.moments(0)[:, 0].sum() == m.sum()
+    assert ctx.moments(0)[:, 6].sum() == sc.disp[m].astype(np.int64).sum()
+
+
+def test_moments_edge_cases(gpu_ctx_factory):
+    W, H = 64, 32
+    ctx = gpu_ctx_factory(width=W, height=H)
+    ctx.frames_alloc(3, 40, 8)
+    rng = np.random.default_rng(3)
+    # frame 0: nothing labelled; frame 1: one superpixel = whole frame, extreme disparities
+    # (incl. negative, the reference's size_t quirk is NOT reproduced: signed int64 sums);
+    # frame 2: salt-and-pepper labels, every pixel a different run
+    d0 = rng.integers(0, 2047, (H, W)).astype(np.int16); l0 = np.full((H, W), 0xFFFF, np.uint16)
+    d1 = rng.choice(np.array([-32768, 32767, 0, 2047], np.int16), (H, W)); l1 = np.zeros((H, W), np.uint16)
+    d2 = rng.integers(0, 2047, (H, W)).astype(np.int16); l2 = rng.integers(0, 40, (H, W)).astype(np.uint16)
+    l2[rng.random((H, W)) < 0.1] = 0xFFFF
+    for f, (d, l, S) in enumerate([(d0, l0, 5), (d1, l1, 1), (d2, l2, 40)]):
+        ctx.frame_upload(f, d, l, S)
+    ctx.frames_moments()
+    for f, (d, l, S) in enumerate([(d0, l0, 5), (d1, l1, 1), (d2, l2, 40)]):
+        assert np.array_equal(ctx.moments(f), O.moments(d, l, S)), f
+    # recomputing is idempotent
+    ctx.frames_moments()
+    assert np.array_equal(ctx.moments(2), O.moments(d2, l2, 40))
+    # the A1 filter: degenerate superpixels are flagged and their edges get q = -1
+    label = np.full((H, W), 0xFFFF, np.uint16); disp = np.full((H, W), 100, np.int16)
+    label[0:3, 0:3] = 0; label[5, 0:12] = 1; label[0:12, 20] = 2
+    label[8:12, 8:12] = 3; disp[8:12, 8:12] = 0; label[12:16, 24:32] = 4
+    ctx.frame_upload(0, disp, label, 5)
+    ctx.frame_set_graph(0, np.array([0, 1, 1, 1, 1, 2], np.uint32), np.array([4, 0], np.uint32))
+    ctx.frames_moments(0, 1); ctx.frames_edge_probs(0, 1)
+    assert ctx.local_fit(0)[1].tolist() == [0, 0, 0, 0, 1]
+    assert (ctx.edge_probs(0) == -1.0).all()
+
+
+def _oracle_chains(sc, n, seed, off=0, **kw):
+    S = sc.n_superpixels
+    fit, valid, _ = O.local_fit(O.moments(sc.disp, sc.label, S), sc.width, sc.height)
+    _, q = O.edge_probs(fit, valid, sc.row_ptr, sc.col)
+    return O.Chains(fit, valid, sc.row_ptr, sc.col, q, n, seed, off, **kw)
+
+
+def _compare_chains(ctx, orc, frame=0, lo=0, hi=None):
+    hi = ctx.n_chains if hi is None else hi
+    S = orc.S
+    gs, os_ = ctx.scalars(), orc.scalars()
+    for k in ("state_hash", "trace_hash", "n_accept", "n_case", "status", "top_count", "top_hash", "overflow"):
+        assert np.array_equal(gs[k][lo:hi], os_[k]), k
+    assert np.array_equal(bits(gs["energy"][lo:hi]), bits(os_["energy"]))
+    assert np.array_equal(bits(gs["best_energy"][lo:hi]), bits(os_["best_energy"]))
+    for which in (0, 1, 2):
+        for canon in (True, False):
+            assert np.array_equal(ctx.labels(which, canon)[lo:hi, :S], orc.labels(which, canon)), (which, canon)
+    assert np.array_equal(bits(ctx.recompute_energy()[lo:hi]), bits(orc.recompute_energy()))
+    assert ctx.visits()[lo:hi] == orc.visits()
+
+
+def test_chain_parity_small(scene_c2_small, gpu_ctx_factory):
+    sc = scene_c2_small
+    ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
+    ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    n = 8
+    ctx.chains_init(n, seed=5)
+    ctx.chains_set_trace(400)
+    ctx.chains_run(100, 300)
+    orc = _oracle_chains(sc, n, seed=5)
+    st, tr = orc.run(100, 300, trace=True)
+    assert st == 0
+    assert np.array_equal(ctx.trace(), tr)             # accept/reject + case sequence, bit-exact
+    _compare_chains(ctx, orc)
+    assert np.array_equal(ctx.marginals(0)[:sc.n_superpixels], orc.marginals())
+    # continue the run: steps carry on, statistics accumulate
+    ctx.chains_run(0, 200)
+    st, tr2 = orc.run(0, 200, trace=True)
+    assert np.array_equal(ctx.trace(), tr2)
+    _compare_chains(ctx, orc)
+    assert np.array_equal(ctx.marginals(0)[:sc.n_superpixels], orc.marginals())
+
+
+def test_chain_offset_sharding(scene_c2_small, gpu_ctx_factory):
+    # a shard that owns chains [6, 10) of a 10-chain job reproduces them exactly (multi-GPU rule)
+    sc = scene_c2_small
+    ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
+    ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(4, seed=11, chain_offset=6)
+    ctx.chains_run(50, 150)
+    orc = _oracle_chains(sc, 10, seed=11)
+    orc.run(50, 150)
+    assert np.array_equal(ctx.scalars()["trace_hash"], orc.scalars()["trace_hash"][6:10])
+    assert np.array_equal(ctx.labels()[:, :sc.n_superpixels], orc.labels()[6:10])
+
+
+def test_chain_parity_c2_full_size(gpu_ctx_factory):
+    # BASELINE config 2 at full size (640x480, ~500 superpixels): a few chains against the oracle,
+    # all 1024 chains checked through size-independent properties.
+    from mcmc_amd.scene import make_scene
+    sc = make_scene(seed=1)
+    ctx = gpu_ctx_factory()
+    ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(1024, seed=1)
+    ctx.chains_run(100, 200)
+    orc = _oracle_chains(sc, 6, seed=1)
+    orc.run(100, 200)
+    _compare_chains(ctx, orc, lo=0, hi=6)
+    s = ctx.scalars()
+    assert (s["status"] == 0).all()
+    assert (s["n_case"].sum(axis=1) == 300).all()
+    assert np.allclose(s["energy"], ctx.recompute_energy(), rtol=1e-9)
+    v = ctx.visits()
+    assert all(sum(d.values()) + int(o) == 200 for d, o in zip(v, s["overflow"]))
+    m = ctx.marginals(0)[:sc.n_superpixels]
+    assert (m.sum(axis=1) == 1024 * 200).all()
+    # determinism: the same seed twice gives identical chains
+    ctx.chains_init(1024, seed=1)
+    ctx.chains_run(100, 200)
+    assert np.array_equal(ctx.scalars()["trace_hash"], s["trace_hash"])
+
+
+def test_chain_parity_large_s_global_tables(gpu_ctx_factory):
+    # tables that do not fit LDS (config 3 style: ~1500 superpixels here) take the HBM/L2-table variant
+    from mcmc_amd.scene import make_scene
+    sc = make_scene(width=960, height=540, n_planes=10, n_superpixels=1500, seed=2)
+    ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
+    ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(6, chains_per_frame=6, seed=3)
+    ctx.chains_set_trace(120)
+    ctx.chains_run(40, 80)
+    orc = _oracle_chains(sc, 6, seed=3)
+    st, tr = orc.run(40, 80, trace=True)
+    assert np.array_equal(ctx.trace(), tr)
+    _compare_chains(ctx, orc)
+
+
+def test_multi_frame_batch(gpu_ctx_factory):
+    # config 5 style: several frames, a few chains each; frame f's chains only see frame f
+    from mcmc_amd.scene import make_scene
+    scenes = [make_scene(width=160, height=120, n_planes=3, n_superpixels=40 + 5 * f, seed=100 + f) for f in range(5)]
+    smax = max(s.n_superpixels for s in scenes); emax = max(s.col.size for s in scenes)
+    ctx = gpu_ctx_factory(width=160, height=120)
+    ctx.frames_alloc(5, smax, emax)
+    for f, sc in enumerate(scenes):
+        _load(ctx, f, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    cpf = 4
+    ctx.chains_init(5 * cpf, chains_per_frame=cpf, seed=21)
+    ctx.chains_run(30, 120)
+    s = ctx.scalars()
+    for f, sc in enumerate(scenes):
+        assert np.array_equal(ctx.moments(f), O.moments(sc.disp, sc.label, sc.n_superpixels))
+        orc = _oracle_chains(sc, cpf, seed=21, off=f * cpf)
+        orc.run(30, 120)
+        assert np.array_equal(s["trace_hash"][f * cpf:(f + 1) * cpf], orc.scalars()["trace_hash"]), f
+        assert np.array_equal(ctx.labels()[f * cpf:(f + 1) * cpf, :sc.n_superpixels], orc.labels())
+        assert np.array_equal(ctx.marginals(f)[:sc.n_superpixels], orc.marginals())
+
+
+def test_error_paths(gpu_ctx_factory):
+    from mcmc_amd import host
+    ctx = gpu_ctx_factory(width=64, height=32)
+    with pytest.raises(host.McmcError):
+        ctx.frames_moments(0, 1)                      # no frames
+    ctx.frames_alloc(1, 10, 10)
+    with pytest.raises(host.McmcError):
+        ctx.frames_moments()                          # not uploaded
+    with pytest.raises(host.McmcError):
+        ctx.chains_init(4)                            # no edge probabilities
+    d = np.full((32, 64), 50, np.int16); l = np.full((32, 64), 0xFFFF, np.uint16)
+    ctx.frame_upload(0, d, l, 3)
+    with pytest.raises(host.McmcError):
+        ctx.frame_set_graph(0, np.array([0, 1, 1, 2], np.uint32), np.array([7, 0], np.uint32))  # id out of range
+    ctx.frame_set_graph(0, np.array([0, 0, 0, 0], np.uint32), np.zeros(0, np.uint32))
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    with pytest.raises(host.McmcError) as e:
+        ctx.chains_init(2)                            # every superpixel fails the filter
+    assert e.value.code == -7
