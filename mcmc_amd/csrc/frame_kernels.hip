@@ -59,7 +59,7 @@ MC_D void slot_flush(const Slot& s, unsigned long long* tab, unsigned long long*
 }
 
 // 8 consecutive pixels of one row, all in superpixel s.lab
-MC_D void slot_add8(Slot& s, int u0, int v, int s1, int sk, uint32_t s2a, uint32_t s2b)
+MC_D void slot_add8(Slot& s, int u0, int v, int s1, int sk, uint64_t s2)
 {
     int g = 8 * u0 + 28;
     s.n += 8;
@@ -71,7 +71,7 @@ MC_D void slot_add8(Slot& s, int u0, int v, int s1, int sk, uint32_t s2a, uint32
     s.sb += s1;
     s.sub += (int64_t)(u0 * s1 + sk);
     s.svb += (int64_t)(v * s1);
-    s.sbb += (int64_t)((uint64_t)s2a + (uint64_t)s2b);
+    s.sbb += (int64_t)s2;
 }
 
 MC_D void slot_add1(Slot& s, int u, int v, int b)
@@ -135,16 +135,18 @@ __global__ __launch_bounds__(1024) void sp_moments_kernel(MomentArgs a)
                     const int b6 = (int)(short)(d4.w & 0xFFFFu), b7 = (int)d4.w >> 16;
                     const int s1 = ((b0 + b1) + (b2 + b3)) + ((b4 + b5) + (b6 + b7));
                     const int sk = (b1 + 2 * b2 + 3 * b3) + (4 * b4 + 5 * b5) + (6 * b6 + 7 * b7);
-                    const uint32_t s2a = (uint32_t)(b0 * b0) + (uint32_t)(b1 * b1) + (uint32_t)(b2 * b2) + (uint32_t)(b3 * b3);
-                    const uint32_t s2b = (uint32_t)(b4 * b4) + (uint32_t)(b5 * b5) + (uint32_t)(b6 * b6) + (uint32_t)(b7 * b7);
-                    if (first == A.lab) { slot_add8(A, u0, v, s1, sk, s2a, s2b); lru = 1; }
-                    else if (first == B.lab) { slot_add8(B, u0, v, s1, sk, s2a, s2b); lru = 0; }
+                    // b*b <= 2^30 (b = -32768): pair sums fit u32, the total needs 64 bits
+                    const uint32_t p01 = (uint32_t)(b0 * b0) + (uint32_t)(b1 * b1), p23 = (uint32_t)(b2 * b2) + (uint32_t)(b3 * b3);
+                    const uint32_t p45 = (uint32_t)(b4 * b4) + (uint32_t)(b5 * b5), p67 = (uint32_t)(b6 * b6) + (uint32_t)(b7 * b7);
+                    const uint64_t s2 = ((uint64_t)p01 + (uint64_t)p23) + ((uint64_t)p45 + (uint64_t)p67);
+                    if (first == A.lab) { slot_add8(A, u0, v, s1, sk, s2); lru = 1; }
+                    else if (first == B.lab) { slot_add8(B, u0, v, s1, sk, s2); lru = 0; }
                     else if (lru == 0) {
                         slot_flush<USE_LDS>(A, tab, gmom); slot_reset(A, first);
-                        slot_add8(A, u0, v, s1, sk, s2a, s2b); lru = 1;
+                        slot_add8(A, u0, v, s1, sk, s2); lru = 1;
                     } else {
                         slot_flush<USE_LDS>(B, tab, gmom); slot_reset(B, first);
-                        slot_add8(B, u0, v, s1, sk, s2a, s2b); lru = 0;
+                        slot_add8(B, u0, v, s1, sk, s2); lru = 0;
                     }
                 }
             } else {
