@@ -335,11 +335,11 @@ int mcmc_frames_moments(mcmc_ctx* c, int first, int count)
     bands = std::min(bands, std::max(1, H / 16));
     if (generic) bands = std::min(H, std::max(bands, 64));
     a.bands = bands;
+    if (bands > 1 || !use_lds)
+        HIPCHK(c, hipMemsetAsync(c->d_mom + (size_t)first * c->s_max * MCMC_MOMENT_STRIDE, 0,
+                                 (size_t)count * c->s_max * MCMC_MOMENT_STRIDE * 8, c->stream));
     {
         Timer t(c, K_MOM);
-        if (bands > 1 || !use_lds)
-            HIPCHK(c, hipMemsetAsync(c->d_mom + (size_t)first * c->s_max * MCMC_MOMENT_STRIDE, 0,
-                                     (size_t)count * c->s_max * MCMC_MOMENT_STRIDE * 8, c->stream));
         HIPCHK(c, launch_moments(a, count, threads, use_lds ? lds : 0, generic, c->stream));
     }
     FitArgs fa{};
