@@ -142,6 +142,9 @@ int mcmc_chains_recompute_energy(mcmc_ctx *ctx, double *out /* n_chains */);
  * 3 chain_step.  Returns milliseconds, < 0 if never launched. */
 double mcmc_last_kernel_ms(mcmc_ctx *ctx, int kernel);
 int mcmc_set_timing(mcmc_ctx *ctx, int enable);
+/* Launch-shape overrides for tuning runs (0 / -1 = automatic): "k1_bands",
+ * "k1_threads", "k1_use_lds".  Results never depend on them (integer sums). */
+int mcmc_ctx_set_option(mcmc_ctx *ctx, const char *name, int value);
 
 /* Device self-test of the deterministic math shared by every kernel: fills
  * out_log[i] = det_log(x[i]), out_exp[i] = det_exp(x[i]),

@@ -62,6 +62,8 @@ struct mcmc_ctx {
     hipEvent_t ev0[K_COUNT]{}, ev1[K_COUNT]{};
     bool ev_valid[K_COUNT]{};
     int chain_variant = 0;
+    // tuning overrides (0 / -1 = automatic)
+    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0;
 };
 
 namespace {
@@ -214,6 +216,18 @@ int mcmc_ctx_synchronize(mcmc_ctx* c)
     return MCMC_OK;
 }
 
+int mcmc_ctx_set_option(mcmc_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return MCMC_E_BADARG;
+    const std::string n(name);
+    if (n == "k1_bands") c->opt_k1_bands = value;
+    else if (n == "k1_threads") c->opt_k1_threads = value;
+    else if (n == "k1_use_lds") c->opt_k1_lds = value;
+    else if (n == "k1_debug") c->opt_k1_debug = value;
+    else return fail(c, MCMC_E_BADARG, "set_option: unknown option " + n);
+    return MCMC_OK;
+}
+
 int mcmc_set_timing(mcmc_ctx* c, int enable)
 {
     if (!c) return MCMC_E_BADARG;
@@ -322,25 +336,34 @@ int mcmc_frames_moments(mcmc_ctx* c, int first, int count)
     MomentArgs a{};
     a.disp = c->d_disp; a.label = c->d_label; a.S = c->d_S; a.mom = c->d_mom;
     a.frame_stride = c->px; a.W = W; a.H = H; a.s_max = c->s_max; a.first_frame = first;
-    const bool generic = (W % 8) != 0;
+    bool generic = (W % 8) != 0;
     int threads = 256;
     if (!generic) {
         const int g = W / 8;  // 16-byte chunks per row
-        if (g <= 512) { int k = std::max(1, 384 / g); threads = g * k; }
-        threads = std::min(threads, 1024);
+        if (g <= 512) { int k = std::max(1, 480 / g); threads = g * k; }
+        threads = std::min(threads, 512);
     }
-    const size_t lds = (size_t)s_used * MCMC_MOMENT_STRIDE * 8;
-    const bool use_lds = !generic && lds <= 64 * 1024;
-    int bands = std::max(1, 2048 / count);
-    bands = std::min(bands, std::max(1, H / 16));
-    if (generic) bands = std::min(H, std::max(bands, 64));
+    if (c->opt_k1_threads > 0 && !generic) threads = std::min(512, c->opt_k1_threads);
+    // LDS: one int64[S][10] table per workgroup + a 6 KB eviction log per wave
+    int mode = generic ? 2 : 0;
+    size_t lds = 0;
+    if (!generic) {
+        lds = moments_lds_bytes(s_used, threads);
+        if (lds > 96 * 1024 || c->opt_k1_lds == 0) { mode = 1; lds = moments_lds_bytes(0, threads); }  // table stays in HBM
+    }
+    int bands = std::max(1, 256 / count);   // about one workgroup per CU; more only splits the LDS tables
+    bands = std::min(bands, std::max(1, H / 32));
+    if (mode == 2) bands = std::min(H, std::max(bands, 64));
+    if (c->opt_k1_bands > 0) bands = std::min(c->opt_k1_bands, H);
     a.bands = bands;
-    if (bands > 1 || !use_lds)
+    a.table_rows = s_used;
+    a.debug = c->opt_k1_debug;
+    if (bands > 1 || mode != 0)
         HIPCHK(c, hipMemsetAsync(c->d_mom + (size_t)first * c->s_max * MCMC_MOMENT_STRIDE, 0,
                                  (size_t)count * c->s_max * MCMC_MOMENT_STRIDE * 8, c->stream));
     {
         Timer t(c, K_MOM);
-        HIPCHK(c, launch_moments(a, count, threads, use_lds ? lds : 0, generic, c->stream));
+        HIPCHK(c, launch_moments(a, count, threads, lds, mode, c->stream));
     }
     FitArgs fa{};
     fa.mom = c->d_mom; fa.S = c->d_S; fa.fit = c->d_fit; fa.valid = c->d_valid; fa.local_err = c->d_lerr;

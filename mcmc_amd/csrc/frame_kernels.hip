@@ -42,9 +42,9 @@ MC_D void slot_reset(Slot& s, uint32_t lab)
 }
 
 template <bool USE_LDS>
-MC_D void slot_flush(const Slot& s, unsigned long long* tab, unsigned long long* gmom)
+MC_D void slot_flush(const Slot& s, unsigned long long* tab, unsigned long long* gmom, int S)
 {
-    if (s.n == 0) return;
+    if (s.n == 0 || s.lab >= (uint32_t)S) return;  // never address outside the S x 10 table
     unsigned long long* t = (USE_LDS ? tab : gmom) + (size_t)s.lab * kMomStride;
     atomicAdd(t + 0, (unsigned long long)(long long)s.n);
     atomicAdd(t + 1, (unsigned long long)(long long)s.su);
@@ -56,22 +56,6 @@ MC_D void slot_flush(const Slot& s, unsigned long long* tab, unsigned long long*
     atomicAdd(t + 7, (unsigned long long)s.sub);
     atomicAdd(t + 8, (unsigned long long)s.svb);
     atomicAdd(t + 9, (unsigned long long)s.sbb);
-}
-
-// 8 consecutive pixels of one row, all in superpixel s.lab
-MC_D void slot_add8(Slot& s, int u0, int v, int s1, int sk, uint64_t s2)
-{
-    int g = 8 * u0 + 28;
-    s.n += 8;
-    s.su += g;
-    s.sv += 8 * v;
-    s.suu += (int64_t)(8 * u0 * u0 + 56 * u0 + 140);
-    s.suv += (int64_t)(v * g);
-    s.svv += (int64_t)(8 * v * v);
-    s.sb += s1;
-    s.sub += (int64_t)(u0 * s1 + sk);
-    s.svb += (int64_t)(v * s1);
-    s.sbb += (int64_t)s2;
 }
 
 MC_D void slot_add1(Slot& s, int u, int v, int b)
@@ -88,102 +72,318 @@ MC_D void slot_add1(Slot& s, int u, int v, int b)
     s.sbb += (int64_t)(b * b);
 }
 
-template <bool USE_LDS>
-__global__ __launch_bounds__(1024) void sp_moments_kernel(MomentArgs a)
+// packed 16-bit helpers: two pixels per dword, exactly as they sit in HBM
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+MC_D uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+MC_D uint32_t pk_sub_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+MC_D uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+MC_D int sdot2(uint32_t a, uint32_t b, int c)
 {
-    extern __shared__ unsigned long long tab[];
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+constexpr uint32_t kOnes = 0x00010001u;
+// (1,1) in the halves of lw that equal the label replicated in pat
+MC_D uint32_t match01(uint32_t lw, uint32_t pat) { return pk_sub_u16(kOnes, pk_min_u16(lw ^ pat, kOnes)); }
+
+// Sums of one 8-pixel chunk (one row v, columns u0..u0+7), all fit 32 bits but sbb.
+struct ChunkSums {
+    int32_t n, su, sv, suu, suv, svv, sb, sub, svb;
+    uint64_t sbb;
+};
+
+// the pixels selected by m01[] (pairs of 0/1); dw[] holds the 8 int16 disparities.  Branch-free.
+MC_D ChunkSums chunk_masked(const uint32_t m01[4], const uint32_t dw[4], int u0, int v)
+{
+    const uint32_t np = (m01[0] + m01[1]) + (m01[2] + m01[3]);
+    const int nc = (int)((np & 0xFFFFu) + (np >> 16));
+    int km = sdot2(m01[0], 0x00010000u, 0);          // sum k   over selected pixels, k = 0..7
+    km = sdot2(m01[1], 0x00030002u, km);
+    km = sdot2(m01[2], 0x00050004u, km);
+    km = sdot2(m01[3], 0x00070006u, km);
+    int k2 = sdot2(m01[0], 0x00010000u, 0);          // sum k^2
+    k2 = sdot2(m01[1], 0x00090004u, k2);
+    k2 = sdot2(m01[2], 0x00190010u, k2);
+    k2 = sdot2(m01[3], 0x00310024u, k2);
+    const uint32_t b0 = pk_mul_lo_u16(dw[0], m01[0]), b1 = pk_mul_lo_u16(dw[1], m01[1]);
+    const uint32_t b2 = pk_mul_lo_u16(dw[2], m01[2]), b3 = pk_mul_lo_u16(dw[3], m01[3]);
+    int s1 = sdot2(b0, kOnes, 0);
+    s1 = sdot2(b1, kOnes, s1); s1 = sdot2(b2, kOnes, s1); s1 = sdot2(b3, kOnes, s1);
+    int sk = sdot2(b0, 0x00010000u, 0);
+    sk = sdot2(b1, 0x00030002u, sk); sk = sdot2(b2, 0x00050004u, sk); sk = sdot2(b3, 0x00070006u, sk);
+    // b*b <= 2^30 each: a pair sum fits 32 bits read as unsigned, the total needs 64
+    const uint32_t q0 = (uint32_t)sdot2(b0, b0, 0), q1 = (uint32_t)sdot2(b1, b1, 0);
+    const uint32_t q2 = (uint32_t)sdot2(b2, b2, 0), q3 = (uint32_t)sdot2(b3, b3, 0);
+    ChunkSums r;
+    r.n = nc;
+    r.su = u0 * nc + km;
+    r.sv = v * nc;
+    r.suu = u0 * (r.su + km) + k2;
+    r.suv = v * r.su;
+    r.svv = v * v * nc;
+    r.sb = s1;
+    r.sub = u0 * s1 + sk;
+    r.svb = v * s1;
+    r.sbb = ((uint64_t)q0 + (uint64_t)q1) + ((uint64_t)q2 + (uint64_t)q3);
+    return r;
+}
+
+// all 8 pixels of the chunk
+MC_D ChunkSums chunk_total(const uint32_t dw[4], int u0, int v)
+{
+    int s1 = sdot2(dw[0], kOnes, 0);
+    s1 = sdot2(dw[1], kOnes, s1); s1 = sdot2(dw[2], kOnes, s1); s1 = sdot2(dw[3], kOnes, s1);
+    int sk = sdot2(dw[0], 0x00010000u, 0);
+    sk = sdot2(dw[1], 0x00030002u, sk); sk = sdot2(dw[2], 0x00050004u, sk); sk = sdot2(dw[3], 0x00070006u, sk);
+    const uint32_t q0 = (uint32_t)sdot2(dw[0], dw[0], 0), q1 = (uint32_t)sdot2(dw[1], dw[1], 0);
+    const uint32_t q2 = (uint32_t)sdot2(dw[2], dw[2], 0), q3 = (uint32_t)sdot2(dw[3], dw[3], 0);
+    ChunkSums r;
+    r.n = 8;
+    r.su = 8 * u0 + 28;
+    r.sv = 8 * v;
+    r.suu = 8 * u0 * u0 + 56 * u0 + 140;
+    r.suv = v * r.su;
+    r.svv = 8 * v * v;
+    r.sb = s1;
+    r.sub = u0 * s1 + sk;
+    r.svb = v * s1;
+    r.sbb = ((uint64_t)q0 + (uint64_t)q1) + ((uint64_t)q2 + (uint64_t)q3);
+    return r;
+}
+
+MC_D ChunkSums chunk_sub(const ChunkSums& a, const ChunkSums& b)
+{
+    ChunkSums r;
+    r.n = a.n - b.n; r.su = a.su - b.su; r.sv = a.sv - b.sv; r.suu = a.suu - b.suu; r.suv = a.suv - b.suv;
+    r.svv = a.svv - b.svv; r.sb = a.sb - b.sb; r.sub = a.sub - b.sub; r.svb = a.svb - b.svb; r.sbb = a.sbb - b.sbb;
+    return r;
+}
+
+MC_D void slot_add_chunk(Slot& s, const ChunkSums& c)
+{
+    s.n += c.n; s.su += c.su; s.sv += c.sv; s.sb += c.sb;
+    s.suu += (int64_t)c.suu; s.suv += (int64_t)c.suv; s.svv += (int64_t)c.svv;
+    s.sub += (int64_t)c.sub; s.svb += (int64_t)c.svb; s.sbb += (int64_t)c.sbb;
+}
+
+MC_D void slot_swap(Slot& a, Slot& b) { Slot t = a; a = b; b = t; }
+
+// label of the first pixel selected by r01[] (pairs of 0/1, not all zero)
+MC_D uint32_t first_label(const uint32_t r01[4], const uint32_t lw[4])
+{
+    uint32_t L = lw[3] >> 16;
+    L = (r01[3] & 0xFFFFu) ? (lw[3] & 0xFFFFu) : L;
+    L = (r01[2] >> 16) ? (lw[2] >> 16) : L;
+    L = (r01[2] & 0xFFFFu) ? (lw[2] & 0xFFFFu) : L;
+    L = (r01[1] >> 16) ? (lw[1] >> 16) : L;
+    L = (r01[1] & 0xFFFFu) ? (lw[1] & 0xFFFFu) : L;
+    L = (r01[0] >> 16) ? (lw[0] >> 16) : L;
+    L = (r01[0] & 0xFFFFu) ? (lw[0] & 0xFFFFu) : L;
+    return L;
+}
+
+// K1 main kernel.  Per lane two accumulator slots: A = the label matched most
+// recently, B = the other.  Per 8-pixel chunk: A gets its pixels by a masked
+// packed-16-bit sum, B gets (chunk total - A's part): exact as long as every
+// pixel of the chunk is in A or B.  A pixel in neither slot (a new superpixel
+// started) evicts B.  Evicted slots are not added to the LDS table one lane at
+// a time (an LDS 64-bit atomic costs the CU ~64 cycles per wave-instruction
+// however few lanes are active): each wave appends them to a private LDS log
+// with plain stores and drains the log 64 records at a time, every lane
+// applying one record with 10 ds_add_u64.  Labels >= S (dropped pixels) are
+// tracked like any other label and discarded when their record is applied.
+constexpr int kLogCap = 32;       // records per wave
+constexpr int kLogStride = 12;    // u64 per record: label + 10 sums + pad (96 B, 16-B aligned)
+
+MC_D void log_apply(const unsigned long long* rec, unsigned long long* tab, int S)
+{
+    const uint32_t lab = (uint32_t)rec[0];
+    if (lab >= (uint32_t)S) return;
+    unsigned long long* t = tab + (size_t)lab * kMomStride;
+#pragma unroll
+    for (int k = 0; k < kMomStride; ++k) atomicAdd(t + k, rec[1 + k]);
+}
+
+MC_D void log_drain(unsigned long long* wlog, int cnt, unsigned long long* tab, int S, int lane)
+{
+    // the last wave of a block may be partial: stride by the lanes that exist (they are 0..nact-1)
+    const int nact = __popcll((unsigned long long)__ballot(true));
+    for (int i = lane; i < cnt; i += nact) log_apply(wlog + (size_t)i * kLogStride, tab, S);
+}
+
+MC_D void log_write(unsigned long long* rec, const Slot& s)
+{
+    rec[0] = (unsigned long long)s.lab;
+    rec[1] = (unsigned long long)(long long)s.n;
+    rec[2] = (unsigned long long)(long long)s.su;
+    rec[3] = (unsigned long long)(long long)s.sv;
+    rec[4] = (unsigned long long)s.suu;
+    rec[5] = (unsigned long long)s.suv;
+    rec[6] = (unsigned long long)s.svv;
+    rec[7] = (unsigned long long)(long long)s.sb;
+    rec[8] = (unsigned long long)s.sub;
+    rec[9] = (unsigned long long)s.svb;
+    rec[10] = (unsigned long long)s.sbb;
+}
+
+// Append the slot of every lane with `pred` to the wave's log (wave-uniform control flow).
+MC_D void log_append(unsigned long long* wlog, int& cnt, bool pred, const Slot& s, unsigned long long* tab, int S, int lane)
+{
+    uint64_t m = __ballot(pred && s.n != 0);
+    while (m) {
+        // take as many of the requesting lanes (lowest first) as the log has room for
+        if (cnt == kLogCap) { log_drain(wlog, cnt, tab, S, lane); cnt = 0; }
+        const int room = kLogCap - cnt;
+        const int rank = mbcnt(m);
+        const bool mine = ((m >> lane) & 1ull) && rank < room;
+        if (mine) log_write(wlog + (size_t)(cnt + rank) * kLogStride, s);
+        const uint64_t taken = __ballot(mine);
+        cnt += __popcll((unsigned long long)taken);
+        m &= ~taken;
+    }
+}
+
+template <bool TABLE_LDS>
+__global__ __launch_bounds__(512) void sp_moments_kernel(MomentArgs a)
+{
+    extern __shared__ unsigned long long lds[];
     const int frame = a.first_frame + (int)blockIdx.y;
     const int band = (int)blockIdx.x;
     const int S = a.S[frame];
     const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-    const int W = a.W, H = a.H;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int W = a.W, H = a.H, G = W / 8;
     unsigned long long* gmom = a.mom + (size_t)frame * a.s_max * kMomStride;
+    // TABLE_LDS: records are applied to an LDS table [table_rows][10] first; otherwise (table too
+    // large for LDS) straight to HBM with 64-bit integer atomics.
+    unsigned long long* tab = TABLE_LDS ? lds : gmom;
+    unsigned long long* wlog = lds + (TABLE_LDS ? (size_t)a.table_rows * kMomStride : 0) + (size_t)wave * kLogCap * kLogStride;
 
-    if (USE_LDS) {
+    if (TABLE_LDS) {
         for (int i = tid; i < S * kMomStride; i += T) tab[i] = 0ull;
         __syncthreads();
     }
+
     const int rows_per_band = (H + a.bands - 1) / a.bands;
     const int r0 = band * rows_per_band;
     const int r1 = min(H, r0 + rows_per_band);
-    if (r0 < r1) {
-        const size_t base = (size_t)frame * a.frame_stride + (size_t)r0 * W;
-        const uint4* dp = reinterpret_cast<const uint4*>(a.disp + base);
-        const uint4* lp = reinterpret_cast<const uint4*>(a.label + base);
-        const int nchunks = (r1 - r0) * (W / 8);
-        int c = tid;
-        int v = r0 + (c * 8) / W;
-        int u0 = (c * 8) % W;
-        const int dv = (T * 8) / W, du = (T * 8) % W;
-
-        Slot A, B;
-        slot_reset(A, 0xFFFFFFFFu);
-        slot_reset(B, 0xFFFFFFFFu);
-        int lru = 0;  // slot to evict next: 0 = A, 1 = B
-
-        for (; c < nchunks; c += T) {
-            const uint4 d4 = dp[c];
-            const uint4 l4 = lp[c];
-            const uint32_t first = l4.x & 0xFFFFu;
-            const uint32_t pat = first | (first << 16);
-            const bool same8 = (l4.x == pat) & (l4.y == pat) & (l4.z == pat) & (l4.w == pat);
-            if (same8) {
-                if (first < (uint32_t)S) {
-                    const int b0 = (int)(short)(d4.x & 0xFFFFu), b1 = (int)d4.x >> 16;
-                    const int b2 = (int)(short)(d4.y & 0xFFFFu), b3 = (int)d4.y >> 16;
-                    const int b4 = (int)(short)(d4.z & 0xFFFFu), b5 = (int)d4.z >> 16;
-                    const int b6 = (int)(short)(d4.w & 0xFFFFu), b7 = (int)d4.w >> 16;
-                    const int s1 = ((b0 + b1) + (b2 + b3)) + ((b4 + b5) + (b6 + b7));
-                    const int sk = (b1 + 2 * b2 + 3 * b3) + (4 * b4 + 5 * b5) + (6 * b6 + 7 * b7);
-                    // b*b <= 2^30 (b = -32768): pair sums fit u32, the total needs 64 bits
-                    const uint32_t p01 = (uint32_t)(b0 * b0) + (uint32_t)(b1 * b1), p23 = (uint32_t)(b2 * b2) + (uint32_t)(b3 * b3);
-                    const uint32_t p45 = (uint32_t)(b4 * b4) + (uint32_t)(b5 * b5), p67 = (uint32_t)(b6 * b6) + (uint32_t)(b7 * b7);
-                    const uint64_t s2 = ((uint64_t)p01 + (uint64_t)p23) + ((uint64_t)p45 + (uint64_t)p67);
-                    if (first == A.lab) { slot_add8(A, u0, v, s1, sk, s2); lru = 1; }
-                    else if (first == B.lab) { slot_add8(B, u0, v, s1, sk, s2); lru = 0; }
-                    else if (lru == 0) {
-                        slot_flush<USE_LDS>(A, tab, gmom); slot_reset(A, first);
-                        slot_add8(A, u0, v, s1, sk, s2); lru = 1;
-                    } else {
-                        slot_flush<USE_LDS>(B, tab, gmom); slot_reset(B, first);
-                        slot_add8(B, u0, v, s1, sk, s2); lru = 0;
-                    }
-                }
-            } else {
-                const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
-                const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t lk = (k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu);
-                    const int bk = (k & 1) ? ((int)dw[k >> 1] >> 16) : (int)(short)(dw[k >> 1] & 0xFFFFu);
-                    if (lk < (uint32_t)S) {
-                        if (lk == A.lab) { slot_add1(A, u0 + k, v, bk); lru = 1; }
-                        else if (lk == B.lab) { slot_add1(B, u0 + k, v, bk); lru = 0; }
-                        else if (lru == 0) {
-                            slot_flush<USE_LDS>(A, tab, gmom); slot_reset(A, lk);
-                            slot_add1(A, u0 + k, v, bk); lru = 1;
-                        } else {
-                            slot_flush<USE_LDS>(B, tab, gmom); slot_reset(B, lk);
-                            slot_add1(B, u0 + k, v, bk); lru = 0;
-                        }
-                    }
-                }
-            }
-            u0 += du; v += dv;
-            if (u0 >= W) { u0 -= W; v += 1; }
-        }
-        slot_flush<USE_LDS>(A, tab, gmom);
-        slot_flush<USE_LDS>(B, tab, gmom);
+    // chunk schedule of this thread: c0, c0 + stride, ... (count of them), chunk = 8 pixels
+    int c0, stride, count;
+    if (T % G == 0) {
+        // T/G sub-bands of consecutive rows: a lane stays on one 8-pixel column strip and walks
+        // DOWN it row by row, so its label changes only once per superpixel
+        const int nsub = T / G, p = tid / G, g = tid % G;
+        const int R = (r1 - r0 + nsub - 1) / nsub;
+        const int rs = r0 + p * R, re = min(r1, rs + R);
+        c0 = (rs - r0) * G + g; stride = G; count = max(0, re - rs);
+    } else {
+        const int nchunks = max(0, r1 - r0) * G;
+        c0 = tid; stride = T; count = tid < nchunks ? (nchunks - tid + T - 1) / T : 0;
     }
-    if (USE_LDS) {
-        __syncthreads();
-        if (a.bands == 1) {
-            for (int i = tid; i < S * kMomStride; i += T) gmom[i] = tab[i];
+    const size_t base = (size_t)frame * a.frame_stride + (size_t)r0 * W;
+    const uint4* dp = reinterpret_cast<const uint4*>(a.disp + base);
+    const uint4* lp = reinterpret_cast<const uint4*>(a.label + base);
+    int v = r0 + (c0 * 8) / W;
+    int u0 = (c0 * 8) % W;
+    const int dv = (stride * 8) / W, du = (stride * 8) % W;
+
+    Slot A, B;
+    slot_reset(A, kNoLabel);   // an empty slot may collect dropped pixels; they are discarded on apply
+    slot_reset(B, kNoLabel);
+    int cnt = 0;               // records in this wave's log (wave-uniform)
+
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 d4 = zero4, l4 = zero4, d4n = zero4, l4n = zero4;
+    if (count > 0) { d4 = dp[c0]; l4 = lp[c0]; }
+    if (count > 1) { d4n = dp[c0 + stride]; l4n = lp[c0 + stride]; }
+    // the wave iterates while any of its lanes has chunks left, so that log appends stay wave-uniform
+    for (int it = 0; __ballot(it < count) != 0; ++it) {
+        // prefetch two chunks ahead
+        uint4 d4nn = zero4, l4nn = zero4;
+        if (it + 2 < count) { d4nn = dp[c0 + (it + 2) * stride]; l4nn = lp[c0 + (it + 2) * stride]; }
+        const bool live = it < count;
+        const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
+        const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
+        if (a.debug == 1) {  // tuning experiment: streaming only
+            A.sb += (int)(((lw[0] ^ lw[1]) ^ (lw[2] ^ lw[3])) ^ ((dw[0] ^ dw[1]) ^ (dw[2] ^ dw[3])));
         } else {
-            for (int i = tid; i < S * kMomStride; i += T) {
-                unsigned long long x = tab[i];
-                if (x) atomicAdd(gmom + i, x);
+            // which pixels are A's, B's, or in neither slot
+            uint32_t mA[4], rest[4];
+            uint32_t anyA = 0, anyB = 0, anyR = 0;
+            {
+                const uint32_t patA = A.lab | (A.lab << 16), patB = B.lab | (B.lab << 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mA[j] = match01(lw[j], patA);
+                    const uint32_t mb = match01(lw[j], patB);
+                    rest[j] = kOnes ^ (mA[j] | mb);
+                    anyA |= mA[j]; anyB |= mb; anyR |= rest[j];
+                }
             }
+            if (!live || a.debug == 2) anyR = 0;
+            // New labels take over the slots this chunk does not match (A first, then B); the old
+            // contents go to the wave's log.
+            const bool evictA = anyR != 0 && anyA == 0;
+            if (a.debug != 3) log_append(wlog, cnt, evictA, A, tab, S, lane);
+            if (evictA) {
+                const uint32_t L1 = first_label(rest, lw);
+                const uint32_t p1 = L1 | (L1 << 16);
+                slot_reset(A, L1);
+                anyR = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mA[j] = match01(lw[j], p1); rest[j] &= ~mA[j]; anyR |= rest[j]; }
+            }
+            const bool evictB = anyR != 0 && anyB == 0;
+            if (a.debug != 3) log_append(wlog, cnt, evictB, B, tab, S, lane);
+            if (evictB) {
+                const uint32_t L2 = first_label(rest, lw);
+                const uint32_t p2 = L2 | (L2 << 16);
+                slot_reset(B, L2);
+                anyR = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rest[j] &= ~match01(lw[j], p2); anyR |= rest[j]; }
+            }
+            const ChunkSums pa = chunk_masked(mA, dw, u0, v);
+            ChunkSums d = chunk_sub(chunk_total(dw, u0, v), pa);   // everything that is not A's
+            if (live) slot_add_chunk(A, pa);
+            // rare: further labels in the same 8 pixels: each becomes its own record
+            uint32_t left = anyR;
+            if (a.debug == 4 || a.debug == 3) left = 0;
+            while (__ballot(left != 0)) {
+                Slot C;
+                slot_reset(C, kNoLabel);
+                const bool has = left != 0;
+                if (has) {
+                    const uint32_t L3 = first_label(rest, lw);
+                    const uint32_t p3 = L3 | (L3 << 16);
+                    uint32_t m3[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { m3[j] = match01(lw[j], p3) & rest[j]; rest[j] &= ~m3[j]; }
+                    const ChunkSums pc = chunk_masked(m3, dw, u0, v);
+                    slot_reset(C, L3);
+                    slot_add_chunk(C, pc);
+                    d = chunk_sub(d, pc);
+                    left = (rest[0] | rest[1]) | (rest[2] | rest[3]);
+                }
+                log_append(wlog, cnt, has, C, tab, S, lane);
+            }
+            if (live) slot_add_chunk(B, d);
+        }
+        d4 = d4n; l4 = l4n; d4n = d4nn; l4n = l4nn;
+        u0 += du; v += dv;
+        if (u0 >= W) { u0 -= W; v += 1; }
+    }
+    log_append(wlog, cnt, true, A, tab, S, lane);
+    log_append(wlog, cnt, true, B, tab, S, lane);
+    log_drain(wlog, cnt, tab, S, lane);
+
+    if (!TABLE_LDS) return;
+    __syncthreads();
+    if (a.bands == 1) {
+        for (int i = tid; i < S * kMomStride; i += T) gmom[i] = tab[i];
+    } else {
+        for (int i = tid; i < S * kMomStride; i += T) {
+            unsigned long long x = tab[i];
+            if (x) atomicAdd(gmom + i, x);
         }
     }
 }
@@ -209,10 +409,10 @@ __global__ void sp_moments_generic_kernel(MomentArgs a)
             const uint32_t l = a.label[base + (size_t)v * W + u];
             const int b = a.disp[base + (size_t)v * W + u];
             if (l >= (uint32_t)S) continue;
-            if (l != A.lab) { slot_flush<false>(A, nullptr, gmom); slot_reset(A, l); }
+            if (l != A.lab) { slot_flush<false>(A, nullptr, gmom, S); slot_reset(A, l); }
             slot_add1(A, u, v, b);
         }
-        slot_flush<false>(A, nullptr, gmom);
+        slot_flush<false>(A, nullptr, gmom, S);
     }
 }
 
@@ -371,12 +571,13 @@ __global__ void selftest_philox_kernel(const uint32_t* ck, uint32_t* out)
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, bool generic, hipStream_t st)
+hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, int mode, hipStream_t st)
 {
+    // mode 0: LDS table + log, 1: log only (HBM atomics per record), 2: generic (any width)
     dim3 grid(a.bands, n_frames);
-    if (generic) {
+    if (mode == 2) {
         hipLaunchKernelGGL(sp_moments_generic_kernel, grid, dim3(256), 0, st, a);
-    } else if (lds_bytes) {
+    } else if (mode == 0) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_kernel<true>),
@@ -386,9 +587,14 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
         }
         hipLaunchKernelGGL(sp_moments_kernel<true>, grid, dim3(threads), lds_bytes, st, a);
     } else {
-        hipLaunchKernelGGL(sp_moments_kernel<false>, grid, dim3(threads), 0, st, a);
+        hipLaunchKernelGGL(sp_moments_kernel<false>, grid, dim3(threads), lds_bytes, st, a);
     }
     return hipGetLastError();
+}
+
+size_t moments_lds_bytes(int table_rows, int threads)
+{
+    return ((size_t)table_rows * kMomStride + (size_t)((threads + 63) / 64) * kLogCap * kLogStride) * 8;
 }
 
 hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st)

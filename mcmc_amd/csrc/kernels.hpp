@@ -12,6 +12,8 @@ struct MomentArgs {
     unsigned long long* mom;   // [F][s_max][10] int64 bit patterns
     size_t frame_stride;       // pixels per frame
     int W, H, s_max, bands, first_frame;
+    int table_rows;            // rows of the LDS table (>= every S in the launch)
+    int debug;                 // tuning experiments only (0 = normal)
 };
 
 struct FitArgs {
@@ -72,7 +74,8 @@ struct ChainArgs {
     int hcap, lmax;
 };
 
-hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, bool generic, hipStream_t st);
+hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, int mode, hipStream_t st);
+size_t moments_lds_bytes(int table_rows, int threads);
 hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st);
 hipError_t launch_edge_prob(const EdgeArgs& a, int n_frames, hipStream_t st);
 hipError_t launch_segment_prob(const SegArgs& a, hipStream_t st);

@@ -84,6 +84,7 @@ def load():
         "mcmc_chains_recompute_energy": (i, [vp, vp]),
         "mcmc_last_kernel_ms": (dbl, [vp, i]),
         "mcmc_set_timing": (i, [vp, i]),
+        "mcmc_ctx_set_option": (i, [vp, C.c_char_p, i]),
         "mcmc_selftest_math": (i, [vp, vp, vp, i, vp, vp, vp]),
         "mcmc_selftest_philox": (i, [vp, vp, vp, vp]),
     }
@@ -246,6 +247,9 @@ class Context:
 
     def set_timing(self, on=True):
         self._ck(self.L.mcmc_set_timing(self.h, int(on)))
+
+    def set_option(self, name, value):
+        self._ck(self.L.mcmc_ctx_set_option(self.h, name.encode(), int(value)))
 
     def last_kernel_ms(self, kernel):
         return float(self.L.mcmc_last_kernel_ms(self.h, kernel))
