@@ -63,7 +63,8 @@ struct mcmc_ctx {
     bool ev_valid[K_COUNT]{};
     int chain_variant = 0;
     // tuning overrides (0 / -1 = automatic)
-    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0;
+    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0;
+    unsigned long long* d_prof = nullptr;
 };
 
 namespace {
@@ -189,7 +190,7 @@ int mcmc_ctx_destroy(mcmc_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     free_chains(c->ch);
     free_frames(c);
-    dfree(c->d_self);
+    dfree(c->d_self); dfree(c->d_prof);
     for (int k = 0; k < K_COUNT; ++k) { (void)hipEventDestroy(c->ev0[k]); (void)hipEventDestroy(c->ev1[k]); }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -224,6 +225,7 @@ int mcmc_ctx_set_option(mcmc_ctx* c, const char* name, int value)
     else if (n == "k1_threads") c->opt_k1_threads = value;
     else if (n == "k1_use_lds") c->opt_k1_lds = value;
     else if (n == "k1_debug") c->opt_k1_debug = value;
+    else if (n == "k3_profile") c->opt_k3_prof = value;
     else return fail(c, MCMC_E_BADARG, "set_option: unknown option " + n);
     return MCMC_OK;
 }
@@ -514,6 +516,11 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
     a.step0 = h.step; a.burn_in = burn_in; a.iters = iters;
     const unsigned long long total = burn_in + iters;
     if (h.trace && total <= h.trace_cap) { a.trace = h.trace; a.trace_stride = total; }
+    if (c->opt_k3_prof) {
+        if (!c->d_prof) { HIPCHK(c, dalloc(&c->d_prof, 16)); }
+        HIPCHK(c, hipMemsetAsync(c->d_prof, 0, 16 * 8, c->stream));
+        a.prof = c->d_prof;
+    }
     int s_used = 0, e_used = 0;
     const int frames_needed = (h.n + h.cpf - 1) / h.cpf;
     for (int f = 0; f < frames_needed; ++f) { s_used = std::max(s_used, c->h_S[f]); e_used = std::max(e_used, (int)c->h_E2[f]); }
@@ -524,6 +531,15 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
         HIPCHK(c, e);
     }
     h.step += total; h.last_steps = total;
+    return MCMC_OK;
+}
+
+int mcmc_chains_get_profile(mcmc_ctx* c, uint64_t* out12)
+{
+    if (!c || !out12 || !c->d_prof) return fail(c, MCMC_E_STATE, "chains_get_profile: set option k3_profile and run first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out12, c->d_prof, 16 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCMC_OK;
 }
 

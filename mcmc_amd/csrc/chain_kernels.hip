@@ -35,20 +35,25 @@ static inline size_t h_al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // ---- RNG: a batch of 256 draws is one Philox block per lane ----------------
 struct Rng {
-    uint32_t w0, w1, w2, w3;
+    uint32_t w0, w1, w2, w3;      // raw words (integer draws)
+    double r0, r1, r2, r3;        // the same draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
     uint32_t k0, k1, step_lo, step_hi;
     int batch;
 };
+
+MC_D double to_unit(uint32_t x) { return (double)x / 4294967295.0; }
 
 MC_D void rng_gen(Rng& g, int batch, int lane)
 {
     u32x4 c = { g.step_lo, g.step_hi, (uint32_t)(batch * 64 + lane), kPhiloxTag };
     u32x4 r = philox4x32_10(c, g.k0, g.k1);
     g.w0 = r.x; g.w1 = r.y; g.w2 = r.z; g.w3 = r.w;
+    // the divisions are done once per batch, off the BFS critical path
+    g.r0 = to_unit(r.x); g.r1 = to_unit(r.y); g.r2 = to_unit(r.z); g.r3 = to_unit(r.w);
     g.batch = batch;
 }
 
-// d is wave-uniform
+// integer draw, d wave-uniform
 MC_D uint32_t rng_uniform_idx(Rng& g, uint32_t d, int lane)
 {
     d = uni(d);
@@ -59,39 +64,49 @@ MC_D uint32_t rng_uniform_idx(Rng& g, uint32_t d, int lane)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(d & 63u));
 }
 
-// d varies by lane (ascending with lane among lanes that `need` a draw)
-MC_D uint32_t rng_varying_idx(Rng& g, uint32_t d, bool need, int lane)
+// unit draw, d wave-uniform
+MC_D double rng_unit_uniform(Rng& g, uint32_t d, int lane)
 {
-    uint32_t res = 0;
+    d = uni(d);
+    const int b = (int)(d >> 8);
+    if (b != g.batch) rng_gen(g, b, lane);
+    const uint32_t ws = (d >> 6) & 3u;
+    const double v = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
+    const uint64_t u = d2u(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)(d & 63u));
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)(d & 63u));
+    return u2d(((uint64_t)hi << 32) | lo);
+}
+
+// unit draws d0 + rank for the lanes that `need` one (rank = 0, 1, 2, ... in lane order)
+MC_D double rng_unit_varying(Rng& g, uint32_t d0, uint32_t rank, bool need, int lane)
+{
+    const uint32_t d = d0 + rank;
+    double res = 0.0;
     uint64_t m = __ballot(need);
-    while (m) {
+    while (m) {  // one pass unless the draws cross a 64-draw block
         const int first = __ffsll((unsigned long long)m) - 1;
-        const uint32_t dfirst = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
-        const int b = (int)(dfirst >> 8);
+        const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)d, first) >> 6;
+        const int b = (int)(blk >> 2);
         if (b != g.batch) rng_gen(g, b, lane);
-        const bool mine = need && ((int)(d >> 8) == b);
-        const int src = (int)(d & 63u);
-        const uint32_t ws = (d >> 6) & 3u;
-        const uint32_t x0 = (uint32_t)__shfl((int)g.w0, src, kWave);
-        const uint32_t x1 = (uint32_t)__shfl((int)g.w1, src, kWave);
-        const uint32_t x2 = (uint32_t)__shfl((int)g.w2, src, kWave);
-        const uint32_t x3 = (uint32_t)__shfl((int)g.w3, src, kWave);
-        const uint32_t v = ws == 0 ? x0 : (ws == 1 ? x1 : (ws == 2 ? x2 : x3));
+        const uint32_t ws = blk & 3u;
+        const double sel = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
+        const bool mine = need && (d >> 6) == blk;
+        const double v = __shfl(sel, (int)(d & 63u), kWave);
         if (mine) res = v;
         m &= ~__ballot(mine);
     }
     return res;
 }
 
-MC_D double to_unit(uint32_t x) { return (double)x / 4294967295.0; }  // rand()/RAND_MAX, inclusive of 1
-
-// idx-th set bit (ascending) of a bitset of NW words; wave-uniform result
-MC_D uint32_t nth_set_bit(const uint32_t* bits, int NW, uint32_t idx, int lane)
+// idx-th set flag (ascending) of a byte-flag array read as NWB 32-bit words (4 flags each,
+// every flag 0 or 1); wave-uniform result = the flag's index
+MC_D uint32_t nth_flag(const uint32_t* words, int NWB, uint32_t idx, int lane)
 {
     uint32_t acc = 0, result = 0xFFFFFFFFu;
-    for (int wb = 0; wb < NW; wb += kWave) {
+    for (int wb = 0; wb < NWB; wb += kWave) {
         const int w = wb + lane;
-        const uint32_t word = w < NW ? bits[w] : 0u;
+        const uint32_t word = w < NWB ? words[w] : 0u;
         const int pc = __popc(word);
         int incl = pc;
 #pragma unroll
@@ -107,7 +122,7 @@ MC_D uint32_t nth_set_bit(const uint32_t* bits, int NW, uint32_t idx, int lane)
             uint32_t ww = word;
             const uint32_t k = here ? rel - excl : 0u;
             for (uint32_t t = 0; t < k; ++t) ww &= ww - 1u;
-            const uint32_t val = (uint32_t)w * 32u + (uint32_t)(__ffs((int)ww) - 1);
+            const uint32_t val = (uint32_t)w * 4u + ((uint32_t)(__ffs((int)ww) - 1) >> 3);
             const uint64_t hm = __ballot(here);
             result = (uint32_t)__builtin_amdgcn_readlane((int)val, __ffsll((unsigned long long)hm) - 1);
             break;
@@ -127,7 +142,7 @@ struct SegFit {
 // ---------------------------------------------------------------------------
 struct LdsLayout {
     size_t fit, q, col, rowp, vlist, sv, wave0, wave_bytes, total;
-    size_t w_label, w_queue, w_segN, w_segP, w_cbits, w_nbits, w_rbits, w_rpre;
+    size_t w_label, w_queue, w_segN, w_segP, w_inC, w_nflag, w_rbits, w_rpre;
 };
 
 __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds)
@@ -146,10 +161,10 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     size_t w = 0;
     L.w_segP = w; w += A((size_t)S * 8);
     L.w_label = w; w += A((size_t)S * 2);
-    L.w_queue = w; w += A((size_t)S * 2);
+    L.w_queue = w; w += A((size_t)S * 8);
     L.w_segN = w; w += A((size_t)S * 2);
-    L.w_cbits = w; w += A(NW * 4);
-    L.w_nbits = w; w += A(NW * 4);
+    L.w_inC = w; w += A((size_t)S);
+    L.w_nflag = w; w += A((size_t)S);
     L.w_rbits = w; w += A(NW * 4);
     L.w_rpre = w; w += A(NW * 4);
     L.wave_bytes = w;
@@ -160,7 +175,18 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
 // ---------------------------------------------------------------------------
 // The chain kernel.
 // ---------------------------------------------------------------------------
-template <int WPB, bool TAB_LDS>
+// PROF: diagnostic build that accumulates shader-clock cycles per phase of the step into
+// a.prof[12] (never used for reported numbers: the stamps serialise the wave).
+#define MC_PHASE(k)                                                    \
+    do {                                                               \
+        if constexpr (PROF) {                                          \
+            const unsigned long long _t = __builtin_readcyclecounter(); \
+            pacc[k] += _t - ptime;                                     \
+            ptime = _t;                                                \
+        }                                                              \
+    } while (0)
+
+template <int WPB, bool TAB_LDS, bool PROF>
 __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -222,10 +248,12 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
     double* segP = reinterpret_cast<double*>(wbase + L.w_segP);
     uint16_t* label = reinterpret_cast<uint16_t*>(wbase + L.w_label);
-    uint16_t* queue = reinterpret_cast<uint16_t*>(wbase + L.w_queue);
+    uint2* queue = reinterpret_cast<uint2*>(wbase + L.w_queue);   // .x = node | degree << 16, .y = first CSR entry
     uint16_t* segN = reinterpret_cast<uint16_t*>(wbase + L.w_segN);
-    uint32_t* cbits = reinterpret_cast<uint32_t*>(wbase + L.w_cbits);
-    uint32_t* nbits = reinterpret_cast<uint32_t*>(wbase + L.w_nbits);
+    uint8_t* inC = wbase + L.w_inC;                                // 1 = in the component
+    uint8_t* nflag = wbase + L.w_nflag;                            // by label: 1 = neighbouring segment
+    uint32_t* nflagw = reinterpret_cast<uint32_t*>(wbase + L.w_nflag);
+    const int NWB = (int)(((size_t)S + 15) & ~(size_t)15) / 4;     // words of the flag arrays (zero padded)
     uint32_t* rbits = reinterpret_cast<uint32_t*>(wbase + L.w_rbits);
     uint32_t* rpre = reinterpret_cast<uint32_t*>(wbase + L.w_rpre);
 
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     double* g_segP = a.segP + (size_t)chain * a.s_max;
     uint16_t* g_segN = a.segN + (size_t)chain * a.s_max;
     for (int i = lane; i < S; i += kWave) { label[i] = g_label[i]; segP[i] = g_segP[i]; segN[i] = g_segN[i]; }
-    for (int w = lane; w < NW; w += kWave) { cbits[w] = 0u; nbits[w] = 0u; }
+    for (int w = lane; w < NWB; w += kWave) { reinterpret_cast<uint32_t*>(inC)[w] = 0u; nflagw[w] = 0u; }
 
     double energy = a.energy[chain], best_energy = a.best_energy[chain];
     uint64_t state_hash = a.state_hash[chain], trace_hash = a.trace_hash[chain];
@@ -308,6 +336,8 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
         dwell = 0;
     };
 
+    unsigned long long pacc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long ptime = PROF ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long total = a.burn_in + a.iters;
     for (unsigned long long ts = 0; ts < total; ++ts) {
         const unsigned long long t = a.step0 + ts;
@@ -320,56 +350,71 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             const uint32_t start = vlist[rng_uniform_idx(g, nd, lane) % (uint32_t)Sv];
             nd += 2;
             const uint32_t orig = label[start];
+            MC_PHASE(0);
 
             // ---- createComponent BFS (Segmentation.cpp:74-120) ----
-            if (lane == 0) { queue[0] = (uint16_t)start; cbits[start >> 5] = 1u << (start & 31u); }
-            uint32_t qn = 1;
-            for (uint32_t head = 0; head < qn; ++head) {
-                const uint32_t i = uni((uint32_t)queue[head]);
-                const uint32_t rs = uni(rowp[i]), re = uni(rowp[i + 1]);
-                for (uint32_t base = rs; base < re; base += kWave) {
-                    const uint32_t e = base + (uint32_t)lane;
-                    const bool act = e < re;
+            // Queue entries carry the node's CSR row so a pop is one LDS read, prefetched an
+            // iteration early when the entry already exists.
+            uint32_t cur_rs = uni(rowp[start]);
+            uint32_t cur_deg = uni(rowp[start + 1]) - cur_rs;
+            if (lane == 0) { queue[0] = make_uint2(start | (cur_deg << 16), cur_rs); inC[start] = 1; }
+            uint32_t qn = 1, head = 0;
+            while (true) {
+                const bool have_next = head + 1 < qn;
+                uint2 nxt = make_uint2(0u, 0u);
+                if (have_next) nxt = queue[head + 1];
+                for (uint32_t base = 0; base < cur_deg; base += kWave) {
+                    const bool act = base + (uint32_t)lane < cur_deg;
+                    const uint32_t e = cur_rs + base + (uint32_t)lane;
                     const uint32_t j = act ? colAt(e) : 0u;
                     const double qe = act ? qv[e] : -1.0;
                     const bool live = act && !(qe < 0.0);
-                    const bool inC = (cbits[j >> 5] >> (j & 31u)) & 1u;
+                    const bool inc = inC[j] != 0;
                     const uint32_t lj = label[j];
-                    const bool elig = live && !inC && lj == orig;
-                    const bool oth = live && !inC && lj != orig;
-                    if (oth) atomicOr(&nbits[lj >> 5], 1u << (lj & 31u));
+                    const bool elig = live && !inc && lj == orig;
+                    const bool oth = live && !inc && lj != orig;
+                    if (oth) nflag[lj] = 1;
                     const uint64_t em = __ballot(elig);
                     if (em) {
-                        const uint32_t xr = rng_varying_idx(g, nd + (uint32_t)mbcnt(em), elig, lane);
+                        const double r = rng_unit_varying(g, nd, (uint32_t)mbcnt(em), elig, lane);
                         nd += (uint32_t)__popcll((unsigned long long)em);
-                        const bool join = elig && (to_unit(xr) < qe);  // strict (Segmentation.cpp:110)
+                        const bool join = elig && (r < qe);  // strict (Segmentation.cpp:110)
                         const uint64_t jm = __ballot(join);
                         if (join) {
-                            queue[qn + (uint32_t)mbcnt(jm)] = (uint16_t)j;
-                            atomicOr(&cbits[j >> 5], 1u << (j & 31u));
+                            inC[j] = 1;
+                            const uint32_t rj = rowp[j], dj = rowp[j + 1] - rj;
+                            queue[qn + (uint32_t)mbcnt(jm)] = make_uint2(j | (dj << 16), rj);
                         }
                         qn += (uint32_t)__popcll((unsigned long long)jm);
                     }
                 }
+                head++;
+                if (head >= qn) break;
+                if (!have_next) nxt = queue[head];
+                const uint32_t ex = uni(nxt.x);
+                cur_rs = uni(nxt.y);
+                cur_deg = ex >> 16;
             }
             const uint32_t csize = qn;
             const bool same = csize == (uint32_t)segN[orig];  // Segmentation.cpp:19
+            MC_PHASE(1);
 
             // ---- selectSegment (Segmentation.cpp:10-57) ----
-            const double u1 = to_unit(rng_uniform_idx(g, nd, lane)); nd += 1;
+            const double u1 = rng_unit_uniform(g, nd, lane); nd += 1;
             int kase; uint32_t next = orig; double ratio;
             if (!same && u1 < nsp) { kase = 1; ratio = nsp; }
             else {
                 int nnl = 0;
-                for (int w = lane; w < NW; w += kWave) nnl += __popc(nbits[w]);
+                for (int w = lane; w < NWB; w += kWave) nnl += __popc(nflagw[w]);
                 const uint32_t numSeg = (uint32_t)wave_sum_i32(nnl) + 1u;
                 const double existing = same ? 1.0 : (1.0 - nsp);
                 const uint32_t idx = rng_uniform_idx(g, nd, lane) % numSeg; nd += 1;
                 if (idx == numSeg - 1u) { kase = 0; next = orig; }
-                else { kase = 2; next = nth_set_bit(nbits, NW, idx, lane); }
+                else { kase = 2; next = nth_flag(nflagw, NWB, idx, lane); }
                 ratio = existing / (double)numSeg;
             }
 
+            MC_PHASE(2);
             double targetL = 1.0, prop = ratio;  // Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic)
             SegFit f1 = { 0.0, 0, 0, 0 }, f2 = { 0.0, 0, 0, 0 };
             int st = 0;
@@ -379,18 +424,19 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 // (Segmentation.cpp:127-146; Graph.cpp:10-33), wave order over the queue
                 double ps = 1.0, pm = 1.0;
                 for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) {
-                    const uint32_t i = queue[h];
-                    const uint32_t rs = rowp[i], re = rowp[i + 1];
+                    const uint2 ent = queue[h];
+                    const uint32_t rs = ent.y, re = ent.y + (ent.x >> 16);
                     for (uint32_t e = rs; e < re; ++e) {
                         const double qe = qv[e];
                         if (qe < 0.0) continue;
                         const uint32_t j = colAt(e);
                         const uint32_t lj = label[j];
-                        if (lj == orig) { if (!((cbits[j >> 5] >> (j & 31u)) & 1u)) ps = ps * (1.0 - qe); }
+                        if (lj == orig) { if (!inC[j]) ps = ps * (1.0 - qe); }
                         else if (kase == 2 && lj == next) pm = pm * (1.0 - qe);
                     }
                 }
                 const double sep = wave_prod_f64(ps);
+                MC_PHASE(3);
 
                 // ---- fused fits of sB2 (code 2) and sB1 (code 1): pass 1, exact sums ----
                 double s2[9], s1[9];
@@ -400,10 +446,10 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 for (int i = lane; i < S; i += kWave) {
                     const uint32_t li = label[i];
                     if (li == kNoLabel) continue;
-                    const bool inC = (cbits[i >> 5] >> (i & 31)) & 1u;
+                    const bool inc = inC[i] != 0;
                     int m;
-                    if (kase == 1) m = inC ? 2 : (li == orig ? 1 : 0);
-                    else m = (inC || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
+                    if (kase == 1) m = inc ? 2 : (li == orig ? 1 : 0);
+                    else m = (inc || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
                     if (m == 2) {
                         const double* f = fit + (size_t)i * kFitStride;
 #pragma unroll
@@ -424,6 +470,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     for (int k = 0; k < 9; ++k) s1[k] = wave_sum_f64(s1[k]);
                     n1 = wave_sum_i32(n1); m1 = wave_min_i32(m1);
                 }
+                MC_PHASE(4);
                 Vec3 th2, d2, th1 = { 0, 0, 0 }, d1 = { 1, 1, 1 };
                 {
                     Sym3 A2 = { s2[0], s2[1], s2[2], s2[3], s2[4], s2[5] };
@@ -435,18 +482,20 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     Vec3 r1 = { s1[6], s1[7], s1[8] };
                     ldl3(A1, r1, th1, d1);
                 }
+                MC_PHASE(5);
                 // ---- pass 2: factor errors at the fused mean (MyMath.h:247-252), wave order ----
                 double e2p = 0.0, e1p = 0.0;
                 for (int i = lane; i < S; i += kWave) {
                     const uint32_t li = label[i];
                     if (li == kNoLabel) continue;
-                    const bool inC = (cbits[i >> 5] >> (i & 31)) & 1u;
+                    const bool inc = inC[i] != 0;
                     int m;
-                    if (kase == 1) m = inC ? 2 : (li == orig ? 1 : 0);
-                    else m = (inC || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
+                    if (kase == 1) m = inc ? 2 : (li == orig ? 1 : 0);
+                    else m = (inc || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
                     if (m == 2) e2p += member_quad(fit + (size_t)i * kFitStride, th2);
                     else if (m == 1) e1p += member_quad(fit + (size_t)i * kFitStride, th1);
                 }
+                MC_PHASE(6);
                 const double err2 = wave_sum_f64(e2p) / inv2var_den;
                 f2.probL = segment_logprob(err2, d2, log_var, &f2.inf_flag);
                 f2.n = n2; f2.minid = m2;
@@ -465,27 +514,30 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 if (targetL != targetL || prop != prop) st = -4;        // Problem.cpp:216-217
             }
 
+            MC_PHASE(7);
             // ---- FastMetropolisHastings::iterate (MCMC.h:218-227) ----
             const double aL = targetL + det_log(prop);
             const double acc = det_exp(aL);
-            const double r = to_unit(rng_uniform_idx(g, nd, lane)); nd += 1;  // always drawn
+            const double r = rng_unit_uniform(g, nd, lane); nd += 1;  // always drawn
             bool accept = true;
             if (aL < 0.0) { if (r > acc) accept = false; }
             if (st != 0) { accept = false; status = st; }
 
+            MC_PHASE(8);
             uint32_t newlab = next;
             if (accept && kase != 0) {
                 flush_stats();  // leaving the current state
+                MC_PHASE(9);
                 // jump (Problem.cpp:32-74) with smallest-member naming
                 const uint32_t L2 = (uint32_t)f2.minid, L1 = (uint32_t)(f1.n ? f1.minid : 0);
                 uint64_t dh = 0;
                 for (int i = lane; i < S; i += kWave) {
                     const uint32_t li = label[i];
                     if (li == kNoLabel) continue;
-                    const bool inC = (cbits[i >> 5] >> (i & 31)) & 1u;
+                    const bool inc = inC[i] != 0;
                     int m;
-                    if (kase == 1) m = inC ? 2 : (li == orig ? 1 : 0);
-                    else m = (inC || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
+                    if (kase == 1) m = inc ? 2 : (li == orig ? 1 : 0);
+                    else m = (inc || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
                     const uint32_t nl = m == 2 ? L2 : (m == 1 ? L1 : li);
                     if (nl != li) {
                         dh += mix64(((uint64_t)i << 32) | nl) - mix64(((uint64_t)i << 32) | li);
@@ -505,11 +557,14 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 }
                 newlab = L2;
             }
+            MC_PHASE(10);
+            if constexpr (PROF) { pacc[12] += csize; pacc[13] += nd; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
             if (accept) n_accept++;
             if (kase == 0) n_case0++; else if (kase == 1) n_case1++; else n_case2++;
 
-            // clear scratch bitsets
-            for (int w = lane; w < NW; w += kWave) { cbits[w] = 0u; nbits[w] = 0u; }
+            // clear the step's scratch flags
+            for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) inC[queue[h].x & 0xFFFFu] = 0;
+            for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
 
             tb = (uint8_t)((accept ? 1 : 0) | (kase << 1));
             const uint64_t wd = (uint64_t)tb | ((uint64_t)start << 8) | ((uint64_t)csize << 24) | ((uint64_t)newlab << 40);
@@ -517,8 +572,13 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
         }
         if (a.trace && lane == 0) a.trace[(size_t)chain * a.trace_stride + ts] = tb;
         if (ts >= a.burn_in && status == 0) dwell++;
+        MC_PHASE(11);
     }
     flush_stats();
+    if constexpr (PROF) {
+        if (lane == 0 && a.prof)
+            for (int k = 0; k < 16; ++k) atomicAdd(a.prof + k, pacc[k]);
+    }
 
     // ---- write the chain back ----
     for (int i = lane; i < S; i += kWave) { g_label[i] = label[i]; g_segP[i] = segP[i]; g_segN[i] = segN[i]; }
@@ -662,18 +722,21 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int WPB, bool TAB>
+template <int WPB, bool TAB, bool PROF = false>
 static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
 {
+    if constexpr (!PROF && WPB == 4 && TAB) {
+        if (a.prof) return launch_variant<4, true, true>(a, s_lds, e2_lds, bytes, st);
+    }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, PROF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
-    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
     return hipGetLastError();
 }
 

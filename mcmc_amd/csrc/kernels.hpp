@@ -71,6 +71,7 @@ struct ChainArgs {
     unsigned long long* marg;  // [F][s_max][lmax]
     unsigned long long* dwell; // [C] post-burn-in steps spent in the current state, not yet booked
     uint8_t* trace; unsigned long long trace_stride; // optional
+    unsigned long long* prof;  // optional: 12 per-phase cycle sums (diagnostic build of the 4-wave LDS variant)
     int hcap, lmax;
 };
 

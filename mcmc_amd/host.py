@@ -85,6 +85,7 @@ def load():
         "mcmc_last_kernel_ms": (dbl, [vp, i]),
         "mcmc_set_timing": (i, [vp, i]),
         "mcmc_ctx_set_option": (i, [vp, C.c_char_p, i]),
+        "mcmc_chains_get_profile": (i, [vp, vp]),
         "mcmc_selftest_math": (i, [vp, vp, vp, i, vp, vp, vp]),
         "mcmc_selftest_philox": (i, [vp, vp, vp, vp]),
     }
@@ -250,6 +251,11 @@ class Context:
 
     def set_option(self, name, value):
         self._ck(self.L.mcmc_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def chain_profile(self):
+        out = np.zeros(16, np.uint64)
+        self._ck(self.L.mcmc_chains_get_profile(self.h, _ptr(out, np.uint64)))
+        return out
 
     def last_kernel_ms(self, kernel):
         return float(self.L.mcmc_last_kernel_ms(self.h, kernel))
