@@ -156,6 +156,63 @@ int mcmc_selftest_math(mcmc_ctx *ctx, const double *x, const double *y, int n, d
                        double *out_exp, double *out_div);
 int mcmc_selftest_philox(mcmc_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
+/* ======================================================================== *
+ * Path B: multiview segmentation over an SPGraph (world graph of several
+ * views).  Replaces SPGraph / MultiviewSegment / MultiviewSegmentation /
+ * MathUtils for the proposal loop of src/exe/PatternedMatcher.cpp:58-130.
+ * ======================================================================== */
+typedef struct mcmc_mv mcmc_mv;
+
+#define MCMC_MV_PLANE_STRIDE 5   /* nx ny nz d det(cov): PlaneModel (include/MathUtils.h) */
+#define MCMC_MV_MOMENT_STRIDE 10 /* N Sx Sy Sz Sxx Sxy Sxz Syy Syz Szz (f64) */
+
+int mcmc_mv_create(int device, mcmc_mv **out);
+int mcmc_mv_destroy(mcmc_mv *mv);
+const char *mcmc_mv_last_error(const mcmc_mv *mv);
+int mcmc_mv_synchronize(mcmc_mv *mv);
+
+/* The SPGraph (include/SPGraph.h:43-86): vertex v owns the XYZ points
+ * points_xyzw[4*pt_ptr[v] .. 4*pt_ptr[v+1]) (SPNode::subCloudCartesian, PCL
+ * PointXYZ = 4 floats, MathUtils.cpp:26); out-edges in CSR form ascending by
+ * target with SPEdge::BernoulliProbability per entry (symmetric). */
+int mcmc_mv_set_graph(mcmc_mv *mv, int n_vertices, const uint32_t *pt_ptr, const float *points_xyzw,
+                      const uint32_t *row_ptr, const uint32_t *col, const double *bernoulli, uint32_t e2);
+/* Per-vertex sufficient statistics of the plane fit (what fitPlaneSVD's
+ * concatenate-and-SVD needs from a vertex); runs once per graph. */
+int mcmc_mv_vertex_moments(mcmc_mv *mv);
+int mcmc_mv_get_vertex_moments(mcmc_mv *mv, double *out /* V*10 */);
+/* MultiviewSegment::computeFitPlane + computeProbability for an explicit vertex
+ * set (MultiviewSegment.cpp:33-96; MathUtils::fitPlaneSVD MathUtils.cpp:22-54;
+ * SPNode::getErrorForPlaneModel SPGraph.cpp:89-104). */
+int mcmc_mv_fit_segment(mcmc_mv *mv, const uint32_t *members, int n_members, double *plane5,
+                        double *probability, double *local_err);
+/* pMerge(theta1, theta2, weights, temperature) for n_pairs pairs of dim-vectors
+ * (GraphUtils.cpp:11-20), host arrays in, host array out. */
+int mcmc_mv_pmerge(mcmc_mv *mv, const float *theta1, const float *theta2, const float *weights, int dim,
+                   int n_pairs, double temperature, double *out);
+
+/* MultiviewSegmentation(graph) per chain (MultiviewSegmentation.cpp:11-69):
+ * Bernoulli every edge, connected components, fit every segment.  Philox key
+ * (seed, chain_offset + k).  max_new_segments bounds the segments split
+ * proposals append (a chain that runs out freezes with MCMC_E_TOO_LARGE);
+ * split_prob is PatternedMatcher.cpp:77's 0.10. */
+int mcmc_mv_chains_init(mcmc_mv *mv, int n_chains, uint32_t seed, uint32_t chain_offset,
+                        int max_new_segments, double split_prob);
+/* `steps` iterations of the loop at PatternedMatcher.cpp:58-130. */
+int mcmc_mv_chains_run(mcmc_mv *mv, uint64_t steps);
+/* Per step of the NEXT run and chain: flags (bit0 accepted, bit1 split proposal,
+ * bit2 skipped: no neighbour segment; 0xFF frozen) and the ratio a. */
+int mcmc_mv_chains_set_trace(mcmc_mv *mv, uint64_t capacity_steps);
+int mcmc_mv_chains_get_trace(mcmc_mv *mv, uint8_t *flags, double *ratio);
+/* which: 0 = SPNodeState::currentSegmentID (the initial partition; the reference
+ * never updates it), 1 = the segments' vertex sets (moved by split proposals). */
+int mcmc_mv_chains_get_labels(mcmc_mv *mv, int which, uint32_t *out /* n_chains*V */);
+int mcmc_mv_chains_get_scalars(mcmc_mv *mv, uint64_t *n_accept, uint64_t *n_split, uint64_t *n_skip,
+                               uint64_t *trace_hash, int32_t *n_segments, int32_t *status);
+int mcmc_mv_chains_get_planes(mcmc_mv *mv, int chain, double *out /* n_segments*5 */);
+/* Device time of the last mcmc_mv_chains_run launch, milliseconds (< 0: none). */
+double mcmc_mv_last_run_ms(mcmc_mv *mv);
+
 #ifdef __cplusplus
 }
 #endif

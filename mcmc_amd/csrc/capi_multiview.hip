@@ -1,0 +1,353 @@
+// capi_multiview.hip -- C ABI of Path B (include/mcmc_amd.h, mcmc_mv_*): the SPGraph resident
+// in HBM (points, per-vertex moments, CSR edges) and per-chain segmentation state.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mcmc_amd.h"
+#include "kernels.hpp"
+
+using namespace mc;
+
+struct mcmc_mv {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int V = 0; uint32_t E2 = 0; size_t P = 0;
+    float4* d_pts = nullptr; uint32_t* d_ptptr = nullptr; double* d_vm = nullptr;
+    uint32_t *d_rowp = nullptr, *d_col = nullptr, *d_erank = nullptr; double* d_q = nullptr;
+    uint8_t* d_mem = nullptr; double* d_out = nullptr;
+    bool have_graph = false, have_vm = false;
+    // chains
+    int n = 0, seg_cap = 0; uint32_t seed = 0, offset = 0; double split_prob = 0.10;
+    unsigned long long step = 0, last_steps = 0, trace_cap = 0;
+    uint16_t *cur = nullptr, *own = nullptr; double *plane = nullptr, *segP = nullptr; uint8_t* pvalid = nullptr;
+    int *nseg = nullptr, *status = nullptr;
+    unsigned long long *n_accept = nullptr, *n_split = nullptr, *n_skip = nullptr, *trace_hash = nullptr;
+    uint8_t* trace = nullptr; double* trace_a = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
+};
+
+namespace {
+
+int mfail(mcmc_mv* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+#define MVCHK(c, expr)                                                                           \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return mfail((c), MCMC_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T> hipError_t mvalloc(T** p, size_t n)
+{
+    *p = nullptr;
+    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+template <typename T> void mvfree(T*& p) { if (p) (void)hipFree(p); p = nullptr; }
+
+void free_graph(mcmc_mv* c)
+{
+    mvfree(c->d_pts); mvfree(c->d_ptptr); mvfree(c->d_vm); mvfree(c->d_rowp); mvfree(c->d_col);
+    mvfree(c->d_erank); mvfree(c->d_q); mvfree(c->d_mem);
+    c->have_graph = c->have_vm = false;
+}
+void free_chains(mcmc_mv* c)
+{
+    mvfree(c->cur); mvfree(c->own); mvfree(c->plane); mvfree(c->segP); mvfree(c->pvalid); mvfree(c->nseg);
+    mvfree(c->status); mvfree(c->n_accept); mvfree(c->n_split); mvfree(c->n_skip); mvfree(c->trace_hash);
+    mvfree(c->trace); mvfree(c->trace_a);
+    c->n = 0; c->trace_cap = 0; c->last_steps = 0;
+}
+MvGraph graph_of(const mcmc_mv* c)
+{
+    MvGraph g{};
+    g.V = c->V; g.pts = c->d_pts; g.pt_ptr = c->d_ptptr; g.vm = c->d_vm; g.rowp = c->d_rowp; g.col = c->d_col;
+    g.q = c->d_q; g.erank = c->d_erank;
+    return g;
+}
+MvChainArgs chain_args_of(const mcmc_mv* c)
+{
+    MvChainArgs a{};
+    a.n_chains = c->n; a.seg_cap = c->seg_cap; a.seed = c->seed; a.chain_offset = c->offset;
+    a.split_prob = c->split_prob; a.cur = c->cur; a.own = c->own; a.plane = c->plane; a.segP = c->segP;
+    a.segP_valid = c->pvalid; a.nseg = c->nseg; a.status = c->status; a.n_accept = c->n_accept;
+    a.n_split = c->n_split; a.n_skip = c->n_skip; a.trace_hash = c->trace_hash;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcmc_mv_create(int device, mcmc_mv** out)
+{
+    if (!out) return MCMC_E_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return MCMC_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MCMC_E_DEVICE;
+    mcmc_mv* c = new mcmc_mv();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        mvalloc(&c->d_out, 8) != hipSuccess) {
+        delete c;
+        return MCMC_E_DEVICE;
+    }
+    *out = c;
+    return MCMC_OK;
+}
+
+int mcmc_mv_destroy(mcmc_mv* c)
+{
+    if (!c) return MCMC_E_BADARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_chains(c); free_graph(c); mvfree(c->d_out);
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MCMC_OK;
+}
+
+const char* mcmc_mv_last_error(const mcmc_mv* c) { return c ? c->err.c_str() : "null context"; }
+
+int mcmc_mv_synchronize(mcmc_mv* c)
+{
+    if (!c) return MCMC_E_BADARG;
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    return MCMC_OK;
+}
+
+int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pts, const uint32_t* rowp,
+                      const uint32_t* col, const double* q, uint32_t e2)
+{
+    if (!c || V <= 0 || V >= 0xFFFF || !pt_ptr || !pts || !rowp || (e2 && (!col || !q)))
+        return mfail(c, MCMC_E_BADARG, "mv_set_graph: bad argument");
+    if (pt_ptr[0] != 0 || rowp[0] != 0 || rowp[V] != e2) return mfail(c, MCMC_E_BADARG, "mv_set_graph: offsets do not span the arrays");
+    for (int v = 0; v < V; ++v) {
+        if (pt_ptr[v + 1] <= pt_ptr[v]) return mfail(c, MCMC_E_BADARG, "mv_set_graph: every vertex needs at least one point");
+        if (rowp[v + 1] < rowp[v]) return mfail(c, MCMC_E_BADARG, "mv_set_graph: row_ptr not monotone");
+        for (uint32_t e = rowp[v]; e < rowp[v + 1]; ++e) {
+            if (col[e] >= (uint32_t)V || col[e] == (uint32_t)v) return mfail(c, MCMC_E_BADARG, "mv_set_graph: bad neighbour id");
+            if (e > rowp[v] && col[e] <= col[e - 1]) return mfail(c, MCMC_E_BADARG, "mv_set_graph: neighbours must ascend");
+        }
+    }
+    if (mv_chain_lds_bytes(V) > 160 * 1024 - 64) return mfail(c, MCMC_E_TOO_LARGE, "mv_set_graph: per-chain state does not fit 160 KB of LDS");
+    // rank of every undirected edge among the (i < j) entries; the mirror entry shares it
+    std::vector<uint32_t> erank(std::max<uint32_t>(e2, 1));
+    uint32_t r = 0;
+    for (int i = 0; i < V; ++i)
+        for (uint32_t e = rowp[i]; e < rowp[i + 1]; ++e)
+            if ((uint32_t)i < col[e]) erank[e] = r++;
+    for (int i = 0; i < V; ++i)
+        for (uint32_t e = rowp[i]; e < rowp[i + 1]; ++e)
+            if ((uint32_t)i > col[e]) {
+                const uint32_t j = col[e];
+                const uint32_t* b = col + rowp[j];
+                const uint32_t* en = col + rowp[j + 1];
+                const uint32_t* it = std::lower_bound(b, en, (uint32_t)i);
+                if (it == en || *it != (uint32_t)i) return mfail(c, MCMC_E_BADARG, "mv_set_graph: adjacency is not symmetric");
+                erank[e] = erank[(size_t)(it - col)];
+            }
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    free_chains(c); free_graph(c);
+    const size_t P = pt_ptr[V];
+    MVCHK(c, mvalloc(&c->d_pts, P)); MVCHK(c, mvalloc(&c->d_ptptr, (size_t)V + 1)); MVCHK(c, mvalloc(&c->d_vm, (size_t)V * 10));
+    MVCHK(c, mvalloc(&c->d_rowp, (size_t)V + 1)); MVCHK(c, mvalloc(&c->d_col, e2)); MVCHK(c, mvalloc(&c->d_erank, e2));
+    MVCHK(c, mvalloc(&c->d_q, e2)); MVCHK(c, mvalloc(&c->d_mem, (size_t)V));
+    MVCHK(c, hipMemcpyAsync(c->d_pts, pts, P * 16, hipMemcpyHostToDevice, c->stream));
+    MVCHK(c, hipMemcpyAsync(c->d_ptptr, pt_ptr, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    MVCHK(c, hipMemcpyAsync(c->d_rowp, rowp, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (e2) {
+        MVCHK(c, hipMemcpyAsync(c->d_col, col, (size_t)e2 * 4, hipMemcpyHostToDevice, c->stream));
+        MVCHK(c, hipMemcpyAsync(c->d_q, q, (size_t)e2 * 8, hipMemcpyHostToDevice, c->stream));
+        MVCHK(c, hipMemcpyAsync(c->d_erank, erank.data(), (size_t)e2 * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    c->V = V; c->E2 = e2; c->P = P; c->have_graph = true;
+    return MCMC_OK;
+}
+
+int mcmc_mv_vertex_moments(mcmc_mv* c)
+{
+    if (!c || !c->have_graph) return mfail(c, MCMC_E_STATE, "mv_vertex_moments: set the graph first");
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, launch_mv_vertex_moments(graph_of(c), c->d_vm, c->stream));
+    c->have_vm = true;
+    return MCMC_OK;
+}
+
+int mcmc_mv_get_vertex_moments(mcmc_mv* c, double* out)
+{
+    if (!c || !out) return mfail(c, MCMC_E_BADARG, "mv_get_vertex_moments: bad argument");
+    if (!c->have_vm) return mfail(c, MCMC_E_STATE, "mv_get_vertex_moments: moments not computed");
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, hipMemcpyAsync(out, c->d_vm, (size_t)c->V * 80, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    return MCMC_OK;
+}
+
+int mcmc_mv_fit_segment(mcmc_mv* c, const uint32_t* members, int n, double* plane5, double* prob, double* lerr)
+{
+    if (!c || !members || n <= 0) return mfail(c, MCMC_E_BADARG, "mv_fit_segment: bad argument");
+    if (!c->have_vm) return mfail(c, MCMC_E_STATE, "mv_fit_segment: vertex moments not computed");
+    std::vector<uint8_t> mem((size_t)c->V, 0);
+    for (int k = 0; k < n; ++k) {
+        if (members[k] >= (uint32_t)c->V) return mfail(c, MCMC_E_BADARG, "mv_fit_segment: vertex id out of range");
+        mem[members[k]] = 1;
+    }
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, hipMemcpyAsync(c->d_mem, mem.data(), (size_t)c->V, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = launch_mv_fit_segment(graph_of(c), c->d_mem, c->d_out, c->stream);
+    if (e == hipErrorInvalidValue) return mfail(c, MCMC_E_TOO_LARGE, "mv_fit_segment: graph too large");
+    MVCHK(c, e);
+    double out[7];
+    MVCHK(c, hipMemcpyAsync(out, c->d_out, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    if (plane5) std::memcpy(plane5, out, 5 * sizeof(double));
+    if (prob) *prob = out[5];
+    if (lerr) *lerr = out[6];
+    return MCMC_OK;
+}
+
+int mcmc_mv_pmerge(mcmc_mv* c, const float* t1, const float* t2, const float* w, int dim, int n, double T, double* out)
+{
+    if (!c || !t1 || !t2 || !w || !out || dim <= 0 || n <= 0) return mfail(c, MCMC_E_BADARG, "mv_pmerge: bad argument");
+    MVCHK(c, hipSetDevice(c->device));
+    float *d1 = nullptr, *d2 = nullptr, *dw = nullptr; double* dout = nullptr;
+    const size_t N = (size_t)n * dim;
+    hipError_t e = mvalloc(&d1, N);
+    if (e == hipSuccess) e = mvalloc(&d2, N);
+    if (e == hipSuccess) e = mvalloc(&dw, (size_t)dim);
+    if (e == hipSuccess) e = mvalloc(&dout, (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d1, t1, N * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, t2, N * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dw, w, (size_t)dim * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_mv_pmerge(d1, d2, dw, dim, n, T, dout, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    mvfree(d1); mvfree(d2); mvfree(dw); mvfree(dout);
+    MVCHK(c, e);
+    return MCMC_OK;
+}
+
+int mcmc_mv_chains_init(mcmc_mv* c, int n_chains, uint32_t seed, uint32_t offset, int max_new, double split_prob)
+{
+    if (!c || n_chains <= 0 || max_new < 0 || !(split_prob >= 0.0 && split_prob <= 1.0))
+        return mfail(c, MCMC_E_BADARG, "mv_chains_init: bad argument");
+    if (!c->have_vm) return mfail(c, MCMC_E_STATE, "mv_chains_init: vertex moments not computed");
+    if ((long long)c->V + max_new >= 0xFFFF) return mfail(c, MCMC_E_TOO_LARGE, "mv_chains_init: segment ids are 16 bit");
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    free_chains(c);
+    c->n = n_chains; c->seg_cap = c->V + max_new; c->seed = seed; c->offset = offset; c->split_prob = split_prob; c->step = 0;
+    const size_t N = (size_t)n_chains, NV = N * c->V, NS = N * c->seg_cap;
+    MVCHK(c, mvalloc(&c->cur, NV)); MVCHK(c, mvalloc(&c->own, NV)); MVCHK(c, mvalloc(&c->plane, NS * 5));
+    MVCHK(c, mvalloc(&c->segP, NS)); MVCHK(c, mvalloc(&c->pvalid, NS)); MVCHK(c, mvalloc(&c->nseg, N));
+    MVCHK(c, mvalloc(&c->status, N)); MVCHK(c, mvalloc(&c->n_accept, N)); MVCHK(c, mvalloc(&c->n_split, N));
+    MVCHK(c, mvalloc(&c->n_skip, N)); MVCHK(c, mvalloc(&c->trace_hash, N));
+    hipError_t e = launch_mv_chain_init(graph_of(c), chain_args_of(c), c->stream);
+    if (e == hipErrorInvalidValue) return mfail(c, MCMC_E_TOO_LARGE, "mv_chains_init: graph too large for LDS");
+    MVCHK(c, e);
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    return MCMC_OK;
+}
+
+int mcmc_mv_chains_set_trace(mcmc_mv* c, uint64_t cap)
+{
+    if (!c || c->n == 0) return mfail(c, MCMC_E_STATE, "mv_chains_set_trace: no chains");
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    mvfree(c->trace); mvfree(c->trace_a); c->trace_cap = 0;
+    if (cap) {
+        MVCHK(c, mvalloc(&c->trace, (size_t)c->n * cap));
+        MVCHK(c, mvalloc(&c->trace_a, (size_t)c->n * cap));
+        c->trace_cap = cap;
+    }
+    return MCMC_OK;
+}
+
+int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
+{
+    if (!c || c->n == 0) return mfail(c, MCMC_E_STATE, "mv_chains_run: mv_chains_init first");
+    MVCHK(c, hipSetDevice(c->device));
+    MvChainArgs a = chain_args_of(c);
+    a.step0 = c->step; a.steps = steps;
+    if (c->trace && steps <= c->trace_cap) { a.trace = c->trace; a.trace_a = c->trace_a; }
+    MVCHK(c, hipEventRecord(c->ev0, c->stream));
+    MVCHK(c, launch_mv_chain_run(graph_of(c), a, c->stream));
+    MVCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    c->step += steps; c->last_steps = steps;
+    return MCMC_OK;
+}
+
+double mcmc_mv_last_run_ms(mcmc_mv* c)
+{
+    if (!c || !c->ev_valid) return -1.0;
+    if (hipSetDevice(c->device) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int mcmc_mv_chains_get_trace(mcmc_mv* c, uint8_t* flags, double* ratio)
+{
+    if (!c || !c->trace || c->last_steps == 0 || c->last_steps > c->trace_cap) return mfail(c, MCMC_E_STATE, "mv_chains_get_trace: no trace recorded");
+    MVCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n * c->last_steps;
+    if (flags) MVCHK(c, hipMemcpyAsync(flags, c->trace, n, hipMemcpyDeviceToHost, c->stream));
+    if (ratio) MVCHK(c, hipMemcpyAsync(ratio, c->trace_a, n * 8, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    return MCMC_OK;
+}
+
+int mcmc_mv_chains_get_labels(mcmc_mv* c, int which, uint32_t* out)
+{
+    if (!c || !out || which < 0 || which > 1) return mfail(c, MCMC_E_BADARG, "mv_chains_get_labels: bad argument");
+    if (c->n == 0) return mfail(c, MCMC_E_STATE, "mv_chains_get_labels: no chains");
+    MVCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n * c->V;
+    std::vector<uint16_t> tmp(n);
+    MVCHK(c, hipMemcpyAsync(tmp.data(), which ? c->own : c->cur, n * 2, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; ++i) out[i] = tmp[i];
+    return MCMC_OK;
+}
+
+int mcmc_mv_chains_get_scalars(mcmc_mv* c, uint64_t* n_accept, uint64_t* n_split, uint64_t* n_skip,
+                               uint64_t* trace_hash, int32_t* nseg, int32_t* status)
+{
+    if (!c || c->n == 0) return mfail(c, MCMC_E_STATE, "mv_chains_get_scalars: no chains");
+    MVCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->n;
+    auto cp = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    };
+    MVCHK(c, cp(n_accept, c->n_accept, N * 8)); MVCHK(c, cp(n_split, c->n_split, N * 8));
+    MVCHK(c, cp(n_skip, c->n_skip, N * 8)); MVCHK(c, cp(trace_hash, c->trace_hash, N * 8));
+    MVCHK(c, cp(nseg, c->nseg, N * 4)); MVCHK(c, cp(status, c->status, N * 4));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    return MCMC_OK;
+}
+
+int mcmc_mv_chains_get_planes(mcmc_mv* c, int chain, double* out)
+{
+    if (!c || !out || chain < 0 || chain >= c->n) return mfail(c, MCMC_E_BADARG, "mv_chains_get_planes: bad argument");
+    MVCHK(c, hipSetDevice(c->device));
+    int ns = 0;
+    MVCHK(c, hipMemcpyAsync(&ns, c->nseg + chain, 4, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    MVCHK(c, hipMemcpyAsync(out, c->plane + (size_t)chain * c->seg_cap * 5, (size_t)ns * 40, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipStreamSynchronize(c->stream));
+    return MCMC_OK;
+}
+
+}  // extern "C"

@@ -90,4 +90,38 @@ hipError_t launch_chain_energy(const ChainArgs& a, double* out, hipStream_t st);
 hipError_t launch_canonical_labels(const uint16_t* src, const uint8_t* valid, const int* S, int s_max,
                                    int n_chains, int chains_per_frame, uint16_t* dst, hipStream_t st);
 
+// ---- Path B (multiview) ------------------------------------------------------
+struct MvGraph {
+    int V;
+    const float4* pts;         // PCL PointXYZ stride: x y z pad
+    const uint32_t* pt_ptr;    // [V+1]
+    const double* vm;          // [V][10] per-vertex moments
+    const uint32_t* rowp;      // [V+1]
+    const uint32_t* col;       // [E2] ascending within a row
+    const double* q;           // [E2] SPEdge::BernoulliProbability
+    const uint32_t* erank;     // [E2] rank of the undirected edge among (i<j) entries
+};
+
+struct MvChainArgs {
+    int n_chains, seg_cap;
+    uint32_t seed, chain_offset;
+    double split_prob;
+    unsigned long long step0, steps;
+    uint16_t* cur;             // [C][V] initial partition ids (never updated, as in the reference)
+    uint16_t* own;             // [C][V] vertex-set membership
+    double* plane;             // [C][seg_cap][5]
+    double* segP;              // [C][seg_cap] cached probability
+    uint8_t* segP_valid;       // [C][seg_cap]
+    int* nseg; int* status;
+    unsigned long long *n_accept, *n_split, *n_skip, *trace_hash;
+    uint8_t* trace; double* trace_a;   // optional [C][steps]
+};
+
+hipError_t launch_mv_vertex_moments(const MvGraph& g, double* out, hipStream_t st);
+hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* out, hipStream_t st);
+hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
+hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
+size_t mv_chain_lds_bytes(int V);
+hipError_t launch_mv_pmerge(const float* t1, const float* t2, const float* w, int dim, int n, double T, double* out, hipStream_t st);
+
 }  // namespace mc

@@ -1,0 +1,621 @@
+// multiview_kernels.hip -- K4: Path B ("Price multiview") proposal evaluation.
+//
+//  mv_vertex_moments_kernel  per-vertex N, sum p, sum p p^T of the XYZ sub-cloud (one wave per vertex)
+//  mv_fit_segment_kernel     fitPlaneSVD + computeProbability of an explicit vertex set
+//  mv_chain_init_kernel      MultiviewSegmentation ctor: Bernoulli edges, connected components, fits
+//  mv_chain_run_kernel       PatternedMatcher step loop: DFS growth, split / transfer proposal,
+//                            two refits, four segment probabilities, accept decision
+//
+// Restates (behaviour, not code): MathUtils.cpp:17-81, SPGraph.cpp:89-104,
+// MultiviewSegment.cpp:33-96, MultiviewSegmentation.cpp:11-274,
+// PatternedMatcher.cpp:58-130.  The plane fit works on pooled second moments
+// (3x3 symmetric eigen-solve in registers) instead of concatenating every point
+// into a 3xN SVD; the L1 residual is not a moment function and takes one pass
+// over the points of the affected segments (16 B per point, PCL PointXYZ stride).
+//
+// One workgroup (4 waves) per chain: the data-dependent DFS is serial per chain,
+// the refits and the point pass use all 256 lanes.  All f64 results are produced
+// by IEEE operations in a fixed, documented order
+// (wave-order sums, det_exp / det_sqrt from + - * / only, fixed Jacobi sweeps).
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mc {
+
+constexpr uint32_t kPhiloxTagMv = 0x4D564D43u;  // "MVMC"
+constexpr int kMvWaves = 4;
+constexpr int kMvThreads = kMvWaves * 64;
+
+MC_HD double det_sqrt(double x)
+{
+    if (x != x) return x;
+    if (x < 0.0) return u2d(0x7FF8000000000000ull);
+    if (x == 0.0) return x;
+    uint64_t u = d2u(x);
+    if (u == 0x7FF0000000000000ull) return x;
+    int e = 0;
+    if ((u >> 52) == 0) { x = x * 18014398509481984.0 * 18014398509481984.0; u = d2u(x); e = -108; }
+    e += (int)(u >> 52) - 1023;
+    const int odd = e & 1;
+    e -= odd;
+    const double m = u2d((u & 0x000FFFFFFFFFFFFFull) | ((uint64_t)(1023 + odd) << 52));
+    double y = (m + 2.0) / 3.0;
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) y = 0.5 * (y + m / y);
+    return y * u2d((uint64_t)(e / 2 + 1023) << 52);
+}
+
+struct Sym33 { double a00, a01, a02, a11, a12, a22; };
+struct Mat33 { double m[3][3]; };
+
+// one Jacobi rotation on the (p, q) plane; k is the third index
+#define MV_ROT(APP, AQQ, APQ, AKP, AKQ, P, Q)                                          \
+    do {                                                                                \
+        const double apq = APQ;                                                         \
+        if (apq != 0.0) {                                                               \
+            const double theta = (AQQ - APP) / (2.0 * apq);                             \
+            const double at = theta < 0.0 ? -theta : theta;                             \
+            double t;                                                                   \
+            if (at > 1e150) t = 1.0 / (2.0 * at);                                       \
+            else t = 1.0 / (at + det_sqrt(at * at + 1.0));                              \
+            if (theta < 0.0) t = -t;                                                    \
+            const double c = 1.0 / det_sqrt(t * t + 1.0), s = t * c;                    \
+            const double akp = AKP, akq = AKQ;                                          \
+            APP = APP - t * apq;                                                        \
+            AQQ = AQQ + t * apq;                                                        \
+            APQ = 0.0;                                                                  \
+            AKP = c * akp - s * akq;                                                    \
+            AKQ = s * akp + c * akq;                                                    \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) {                             \
+                const double vip = V.m[i][P], viq = V.m[i][Q];                          \
+                V.m[i][P] = c * vip - s * viq;                                          \
+                V.m[i][Q] = s * vip + c * viq;                                          \
+            }                                                                           \
+        }                                                                               \
+    } while (0)
+
+// fitPlaneSVD on pooled moments m[10] -> plane[5] = nx ny nz d det(cov)
+MC_HD void plane_from_moments(const double* m, double* plane)
+{
+    const double N = m[0];
+    const double cx = m[1] / N, cy = m[2] / N, cz = m[3] / N;
+    Sym33 A;
+    A.a00 = m[4] - cx * m[1]; A.a01 = m[5] - cx * m[2]; A.a02 = m[6] - cx * m[3];
+    A.a11 = m[7] - cy * m[2]; A.a12 = m[8] - cy * m[3]; A.a22 = m[9] - cz * m[3];
+    Mat33 V;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V.m[i][j] = i == j ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        MV_ROT(A.a00, A.a11, A.a01, A.a02, A.a12, 0, 1);   // (p,q) = (0,1), k = 2
+        MV_ROT(A.a00, A.a22, A.a02, A.a01, A.a12, 0, 2);   // (0,2), k = 1
+        MV_ROT(A.a11, A.a22, A.a12, A.a01, A.a02, 1, 2);   // (1,2), k = 0
+    }
+    int k = 0;
+    double best = A.a00;
+    if (A.a11 < best) { k = 1; best = A.a11; }
+    if (A.a22 < best) { k = 2; best = A.a22; }
+    const double nx = k == 0 ? V.m[0][0] : (k == 1 ? V.m[0][1] : V.m[0][2]);
+    const double ny = k == 0 ? V.m[1][0] : (k == 1 ? V.m[1][1] : V.m[1][2]);
+    const double nz = k == 0 ? V.m[2][0] : (k == 1 ? V.m[2][1] : V.m[2][2]);
+    plane[0] = nx; plane[1] = ny; plane[2] = nz;
+    plane[3] = (nx * cx + ny * cy) + nz * cz;                 // + n.centroid (sic, MathUtils.cpp:41)
+    plane[4] = ((A.a00 * A.a11) * A.a22) / 8.0;               // det(U S^2 U^T / 2), MathUtils.cpp:45
+}
+
+MC_HD double prob_from_error(double err, double det)
+{
+    double p = det_exp(-err / 2.0) * det_sqrt((2.0 * 3.14159265358979323846) * det);
+    if (p != p) p = 0.0;                                      // MultiviewSegment.cpp:86-91
+    return p;
+}
+
+// mean |n.p + d| over the points of vertex v, wave order (one wave, all lanes return it)
+MC_D double vertex_error(const float4* pts, uint32_t b, uint32_t e, const double* pl, int lane)
+{
+    const double nx = pl[0], ny = pl[1], nz = pl[2], d0 = pl[3];
+    double part = 0.0;
+    for (uint32_t i = b + (uint32_t)lane; i < e; i += kWave) {
+        const float4 p = pts[i];
+        const double d = (((nx * (double)p.x) + (ny * (double)p.y)) + (nz * (double)p.z)) + d0;
+        part += d < 0.0 ? -d : d;
+    }
+    return wave_sum_f64(part) / (double)(e - b);
+}
+
+__global__ __launch_bounds__(256) void mv_vertex_moments_kernel(MvGraph g, double* out)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int v = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (v >= g.V) return;
+    const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
+    double a[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) a[k] = 0.0;
+    for (uint32_t i = b + (uint32_t)lane; i < e; i += kWave) {
+        const float4 p = g.pts[i];
+        const double x = p.x, y = p.y, z = p.z;
+        a[0] += 1.0; a[1] += x; a[2] += y; a[3] += z;
+        a[4] += x * x; a[5] += x * y; a[6] += x * z; a[7] += y * y; a[8] += y * z; a[9] += z * z;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) a[k] = wave_sum_f64(a[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) out[(size_t)v * 10 + k] = a[k];
+}
+
+// pooled moments of the vertices selected by pred(v), wave order by vertex id (one wave)
+template <typename Pred>
+MC_D int pool_moments(const double* vm, int V, int lane, Pred pred, double* m)
+{
+    double a[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) a[k] = 0.0;
+    int n = 0;
+    for (int v = lane; v < V; v += kWave) {
+        if (!pred(v)) continue;
+        n++;
+        const double* r = vm + (size_t)v * 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) a[k] += r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m[k] = wave_sum_f64(a[k]);
+    return wave_sum_i32(n);
+}
+
+// Segment(members): mem[v] != 0 marks members.  One workgroup of 4 waves.
+__global__ __launch_bounds__(kMvThreads) void mv_fit_segment_kernel(MvGraph g, const uint8_t* mem, double* out /*7*/)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* errv = reinterpret_cast<double*>(smem);
+    double* pl = errv + g.V;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        double m[10], p5[5];
+        pool_moments(g.vm, g.V, lane, [&](int v) { return mem[v] != 0; }, m);
+        plane_from_moments(m, p5);
+        if (lane == 0) for (int k = 0; k < 5; ++k) pl[k] = p5[k];
+    }
+    __syncthreads();
+    for (int v = wave; v < g.V; v += kMvWaves) {
+        if (!mem[v]) continue;
+        const double ev = vertex_error(g.pts, g.pt_ptr[v], g.pt_ptr[v + 1], pl, lane);
+        if (lane == 0) errv[v] = ev;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double part = 0.0;
+        for (int v = lane; v < g.V; v += kWave) if (mem[v]) part += errv[v];
+        const double err = wave_sum_f64(part);
+        if (lane == 0) {
+            for (int k = 0; k < 5; ++k) out[k] = pl[k];
+            out[5] = prob_from_error(err, pl[4]);
+            out[6] = err;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// chains
+// ---------------------------------------------------------------------------
+struct MvShared {
+    uint32_t rbuf[256];
+    double pl[4][5];
+    double P[4];
+    int have[4];        // P[k] came from the cache
+    uint32_t start, orig, target, nE, nd;
+    int kind;           // 0 transfer, 1 split, 2 skipped (no neighbour segment), 3 segment table full
+    int nn;
+    double a;
+};
+
+struct MvRng { uint32_t k0, k1, lo, hi; };
+
+// draw d of the step, serial use by one thread: a block's four words are produced at its
+// first use (d & 255 < 64) and kept in LDS for draws d + 64, d + 128, d + 192
+MC_D uint32_t mv_draw(const MvRng& g, uint32_t d, uint32_t* rbuf)
+{
+    const uint32_t i = d & 255u;
+    if (i < 64u) {
+        u32x4 c = { g.lo, g.hi, (d >> 8) * 64u + i, kPhiloxTagMv };
+        const u32x4 r = philox4x32_10(c, g.k0, g.k1);
+        rbuf[i] = r.x; rbuf[64 + i] = r.y; rbuf[128 + i] = r.z; rbuf[192 + i] = r.w;
+        return r.x;
+    }
+    return rbuf[i];
+}
+// random access (no LDS): any draw index
+MC_D uint32_t mv_draw_at(const MvRng& g, uint32_t d)
+{
+    u32x4 c = { g.lo, g.hi, (d >> 8) * 64u + (d & 63u), kPhiloxTagMv };
+    const u32x4 r = philox4x32_10(c, g.k0, g.k1);
+    const uint32_t w = (d >> 6) & 3u;
+    return w == 0 ? r.x : (w == 1 ? r.y : (w == 2 ? r.z : r.w));
+}
+MC_D double mv_unit(uint32_t x) { return (double)x / 4294967295.0; }
+
+struct MvLds {
+    uint16_t *cur, *own, *elist, *sv;
+    uint8_t *inE, *nb;
+    uint32_t* se;
+    double* errv;       // [4][V]
+    MvShared* sh;
+};
+
+__host__ __device__ inline size_t mv_lds_bytes(int V)
+{
+    auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    return A(sizeof(MvShared)) + A((size_t)V * 32) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
+}
+
+MC_D MvLds mv_carve(unsigned char* smem, int V)
+{
+    auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    MvLds L;
+    size_t o = 0;
+    L.sh = reinterpret_cast<MvShared*>(smem + o); o += A(sizeof(MvShared));
+    L.errv = reinterpret_cast<double*>(smem + o); o += A((size_t)V * 32);
+    L.se = reinterpret_cast<uint32_t*>(smem + o); o += A((size_t)V * 4);
+    L.cur = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
+    L.own = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
+    L.elist = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
+    L.sv = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
+    L.inE = smem + o; o += A((size_t)V);
+    L.nb = smem + o;
+    return L;
+}
+
+// MultiviewSegmentation ctor (MultiviewSegmentation.cpp:11-69)
+__global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, MvChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int V = g.V;
+    MvLds L = mv_carve(smem, V);
+    const int chain = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int v = tid; v < V; v += kMvThreads) L.cur[v] = 0xFFFFu;
+    __syncthreads();
+    if (tid == 0) {
+        MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, 0xFFFFFFFFu, 0xFFFFFFFFu };
+        int ncomp = 0;
+        for (int s = 0; s < V; ++s) {
+            if (L.cur[s] != 0xFFFFu) continue;
+            int sp = 0;
+            L.sv[sp++] = (uint16_t)s; L.cur[s] = (uint16_t)ncomp;
+            while (sp) {
+                const int v = L.sv[--sp];
+                const uint32_t e1 = g.rowp[v + 1];
+                for (uint32_t e = g.rowp[v]; e < e1; ++e) {
+                    const uint32_t j = g.col[e];
+                    if (L.cur[j] != 0xFFFFu) continue;
+                    const double u = mv_unit(mv_draw_at(rg, g.erank[e]));
+                    if (u <= g.q[e]) { L.cur[j] = (uint16_t)ncomp; L.sv[sp++] = (uint16_t)j; }
+                }
+            }
+            ncomp++;
+        }
+        L.sh->nn = ncomp;
+    }
+    __syncthreads();
+    const int nseg = L.sh->nn;
+    uint16_t* gcur = a.cur + (size_t)chain * V;
+    uint16_t* gown = a.own + (size_t)chain * V;
+    for (int v = tid; v < V; v += kMvThreads) { gcur[v] = L.cur[v]; gown[v] = L.cur[v]; }
+    double* planes = a.plane + (size_t)chain * a.seg_cap * 5;
+    uint8_t* pvalid = a.segP_valid + (size_t)chain * a.seg_cap;
+    for (int s = tid; s < a.seg_cap; s += kMvThreads) pvalid[s] = 0;
+    for (int s = wave; s < nseg; s += kMvWaves) {
+        double m[10], p5[5];
+        pool_moments(g.vm, V, lane, [&](int v) { return L.cur[v] == (uint16_t)s; }, m);
+        plane_from_moments(m, p5);
+        if (lane == 0) for (int k = 0; k < 5; ++k) planes[(size_t)s * 5 + k] = p5[k];
+    }
+    if (tid == 0) {
+        a.nseg[chain] = nseg; a.status[chain] = 0;
+        a.n_accept[chain] = 0ull; a.n_split[chain] = 0ull; a.n_skip[chain] = 0ull; a.trace_hash[chain] = 0ull;
+    }
+}
+
+// PatternedMatcher.cpp:58-130, `steps` iterations per launch
+__global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int V = g.V;
+    MvLds L = mv_carve(smem, V);
+    MvShared* sh = L.sh;
+    const int chain = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint16_t* gcur = a.cur + (size_t)chain * V;
+    uint16_t* gown = a.own + (size_t)chain * V;
+    double* planes = a.plane + (size_t)chain * a.seg_cap * 5;
+    double* segP = a.segP + (size_t)chain * a.seg_cap;
+    uint8_t* pvalid = a.segP_valid + (size_t)chain * a.seg_cap;
+    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
+    int nseg = a.nseg[chain], status = a.status[chain];
+    unsigned long long n_accept = a.n_accept[chain], n_split = a.n_split[chain], n_skip = a.n_skip[chain];
+    unsigned long long trace_hash = a.trace_hash[chain];
+    __syncthreads();
+
+    for (unsigned long long ts = 0; ts < a.steps; ++ts) {
+        const unsigned long long t = a.step0 + ts;
+        if (status != 0) {
+            if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.steps + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.steps + ts] = 0.0; }
+            continue;
+        }
+        MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
+        // ---- phase 1a (serial): start vertex, DFS growth, move type ----
+        if (tid == 0) {
+            uint32_t nd = 0;
+            const uint32_t start = mv_draw(rg, nd++, sh->rbuf) % (uint32_t)V;
+            uint32_t nE = 1; int sp = 1;
+            L.inE[start] = 1; L.elist[0] = (uint16_t)start; L.sv[0] = (uint16_t)start; L.se[0] = g.rowp[start];
+            const uint16_t cs = L.cur[start];
+            while (sp) {
+                const uint32_t v = L.sv[sp - 1];
+                const uint32_t e = L.se[sp - 1];
+                if (e >= g.rowp[v + 1]) { sp--; continue; }
+                L.se[sp - 1] = e + 1;
+                const uint32_t j = g.col[e];
+                if (L.cur[j] != cs) continue;
+                if (L.inE[j]) continue;
+                const double u = mv_unit(mv_draw(rg, nd++, sh->rbuf));
+                if (u <= g.q[e]) {
+                    L.inE[j] = 1; L.elist[nE++] = (uint16_t)j;
+                    L.sv[sp] = (uint16_t)j; L.se[sp] = g.rowp[j]; sp++;
+                }
+            }
+            const double moveType = mv_unit(mv_draw(rg, nd++, sh->rbuf));
+            sh->start = start; sh->orig = L.own[start]; sh->nE = nE; sh->nd = nd;
+            int kind = 0;
+            if (moveType < a.split_prob) {
+                kind = n_split >= (unsigned long long)(a.seg_cap - V) ? 3 : 1;   // max_new_segments used up
+                sh->target = (uint32_t)nseg;
+            }
+            sh->kind = kind; sh->a = 0.0;
+        }
+        __syncthreads();
+        const uint32_t nE = sh->nE, orig = sh->orig;
+        int kind = sh->kind;
+        if (kind == 3) {
+            status = -6;
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
+            if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.steps + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.steps + ts] = 0.0; }
+            __syncthreads();
+            continue;
+        }
+        if (kind == 1) {
+            // addNewSegment (MultiviewSegmentation.cpp:85-110): the vertices really move
+            const uint32_t tg = sh->target;
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) {
+                const uint32_t v = L.elist[i];
+                pvalid[L.own[v]] = 0;
+                L.own[v] = (uint16_t)tg;
+            }
+            if (tid == 0) pvalid[tg] = 0;
+            nseg++; n_split++;
+        } else {
+            // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids
+            const uint16_t cs = L.cur[sh->start];
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) {
+                const uint32_t v = L.elist[i];
+                const uint32_t e1 = g.rowp[v + 1];
+                for (uint32_t e = g.rowp[v]; e < e1; ++e) {
+                    const uint16_t sj = L.cur[g.col[e]];
+                    if (sj != cs) L.nb[sj] = 1;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                int nn = 0;
+                for (int b = 0; b < V; b += kWave) {
+                    const int s = b + lane;
+                    nn += __popcll((unsigned long long)__ballot(s < V && L.nb[s] != 0));
+                }
+                uint32_t target = 0;
+                if (nn >= 1) {
+                    // round(randbetween(0, n-1)) (PatternedMatcher.cpp:93)
+                    const double x = (double)(nn - 1) * mv_unit(mv_draw_at(rg, sh->nd));
+                    const int idx = (int)(x + 0.5);
+                    int seen = 0;
+                    for (int b = 0; b < V; b += kWave) {
+                        const int s = b + lane;
+                        const uint64_t m = __ballot(s < V && L.nb[s] != 0);
+                        const int c = __popcll((unsigned long long)m);
+                        if (idx < seen + c) {
+                            uint64_t mm = m;
+                            for (int r = 0; r < idx - seen; ++r) mm &= mm - 1ull;
+                            target = (uint32_t)(b + __ffsll((unsigned long long)mm) - 1);
+                            break;
+                        }
+                        seen += c;
+                    }
+                }
+                if (lane == 0) { sh->nn = nn; sh->target = target; if (nn >= 1) sh->nd = sh->nd + 1; else sh->kind = 2; }
+            }
+        }
+        __syncthreads();
+        kind = sh->kind;
+        const uint32_t target = sh->target;
+        if (kind != 2) {
+            // ---- phase 2: planes of SA1, SA2, SB1, SB2 (one wave each) ----
+            auto member = [&](int k, int v) -> bool {
+                const uint32_t o = L.own[v];
+                if (k == 0) return o == orig;
+                if (k == 1) return o == target;
+                if (k == 2) return o == orig && !L.inE[v];
+                return o == target || L.inE[v];
+            };
+            {
+                double m[10], p5[5];
+                int cached = 0;
+                if (wave == 0) {
+                    for (int k = 0; k < 5; ++k) p5[k] = planes[(size_t)orig * 5 + k];
+                    cached = pvalid[orig];
+                } else if (wave == 1) {
+                    if (kind == 1) {
+                        pool_moments(g.vm, V, lane, [&](int v) { return L.inE[v] != 0; }, m);
+                        plane_from_moments(m, p5);
+                        if (lane == 0) for (int k = 0; k < 5; ++k) planes[(size_t)target * 5 + k] = p5[k];
+                    } else {
+                        for (int k = 0; k < 5; ++k) p5[k] = planes[(size_t)target * 5 + k];
+                        cached = pvalid[target];
+                    }
+                } else if (wave == 2) {
+                    const int n = pool_moments(g.vm, V, lane, [&](int v) { return member(2, v); }, m);
+                    if (n > 0) plane_from_moments(m, p5);
+                    else for (int k = 0; k < 5; ++k) p5[k] = planes[(size_t)orig * 5 + k];   // fit skipped (:37)
+                } else {
+                    pool_moments(g.vm, V, lane, [&](int v) { return member(3, v); }, m);
+                    plane_from_moments(m, p5);
+                }
+                if (lane == 0) {
+                    for (int k = 0; k < 5; ++k) sh->pl[wave][k] = p5[k];
+                    sh->have[wave] = cached;
+                    if (cached) sh->P[wave] = segP[wave == 0 ? orig : target];
+                }
+            }
+            __syncthreads();
+            // ---- phase 3: L1 residual pass over the points of the four sets ----
+            const int h0 = sh->have[0], h1 = sh->have[1];
+            for (int v = wave; v < V; v += kMvWaves) {
+                const uint32_t o = L.own[v];
+                const bool ie = L.inE[v] != 0;
+                const bool m0 = !h0 && o == orig, m1 = !h1 && o == target;
+                const bool m2 = o == orig && !ie, m3 = o == target || ie;
+                if (!(m0 || m1 || m2 || m3)) continue;
+                const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
+                if (m0) { const double x = vertex_error(g.pts, b, e, sh->pl[0], lane); if (lane == 0) L.errv[v] = x; }
+                if (m1) { const double x = vertex_error(g.pts, b, e, sh->pl[1], lane); if (lane == 0) L.errv[V + v] = x; }
+                if (m2) { const double x = vertex_error(g.pts, b, e, sh->pl[2], lane); if (lane == 0) L.errv[2 * V + v] = x; }
+                if (m3) { const double x = vertex_error(g.pts, b, e, sh->pl[3], lane); if (lane == 0) L.errv[3 * V + v] = x; }
+            }
+            __syncthreads();
+            // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
+            if (!sh->have[wave]) {
+                double part = 0.0;
+                for (int v = lane; v < V; v += kWave) if (member(wave, v)) part += L.errv[(size_t)wave * V + v];
+                const double err = wave_sum_f64(part);
+                const double p = prob_from_error(err, sh->pl[wave][4]);
+                if (lane == 0) {
+                    sh->P[wave] = p;
+                    if (wave < 2) { const uint32_t sg = wave == 0 ? orig : target; segP[sg] = p; pvalid[sg] = 1; }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- phase 5: computeProposalRatio + accept (MultiviewSegmentation.cpp:270-274; PatternedMatcher.cpp:111-112) ----
+        uint8_t flags = kind == 1 ? 2 : (kind == 2 ? 4 : 0);
+        double av = 0.0;
+        if (kind != 2) {
+            av = (sh->P[2] / sh->P[0]) * (sh->P[3] / sh->P[1]);
+            const double u = mv_unit(mv_draw_at(rg, sh->nd));
+            if (u < av) { flags |= 1; n_accept++; }
+        } else {
+            n_skip++;
+        }
+        trace_hash = mix64(mix64(trace_hash ^ ((uint64_t)flags | ((uint64_t)sh->start << 8) | ((uint64_t)nE << 32))) ^ d2u(av));
+        if (tid == 0 && a.trace) {
+            a.trace[(size_t)chain * a.steps + ts] = flags;
+            if (a.trace_a) a.trace_a[(size_t)chain * a.steps + ts] = av;
+        }
+        // clear the step's flags
+        for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
+        if (kind != 1) for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
+        __syncthreads();
+    }
+    for (int v = tid; v < V; v += kMvThreads) gown[v] = L.own[v];
+    if (tid == 0) {
+        a.nseg[chain] = nseg; a.status[chain] = status;
+        a.n_accept[chain] = n_accept; a.n_split[chain] = n_split; a.n_skip[chain] = n_skip;
+        a.trace_hash[chain] = trace_hash;
+    }
+}
+
+// pMerge (GraphUtils.cpp:11-20): exp(-|w (.) |t2 - t1||^2 T / 2); one thread per pair
+__global__ void mv_pmerge_kernel(const float* t1, const float* t2, const float* w, int dim, int n, double T, double* out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) {
+        double d = (double)t2[(size_t)i * dim + k] - (double)t1[(size_t)i * dim + k];
+        if (d < 0.0) d = -d;
+        const double e = (double)w[k] * d;
+        s += e * e;
+    }
+    out[i] = det_exp(-s * T / 2.0);
+}
+
+hipError_t launch_mv_pmerge(const float* t1, const float* t2, const float* w, int dim, int n, double T, double* out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mv_pmerge_kernel, dim3((n + 127) / 128), dim3(128), 0, st, t1, t2, w, dim, n, T, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_mv_vertex_moments(const MvGraph& g, double* out, hipStream_t st)
+{
+    if (g.V <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mv_vertex_moments_kernel, dim3((g.V + 3) / 4), dim3(256), 0, st, g, out);
+    return hipGetLastError();
+}
+
+size_t mv_chain_lds_bytes(int V) { return mv_lds_bytes(V); }
+
+static hipError_t mv_set_lds_attr()
+{
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_init_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_fit_segment_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    done = true;
+    return hipSuccess;
+}
+
+hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* out, hipStream_t st)
+{
+    hipError_t e = mv_set_lds_attr();
+    if (e != hipSuccess) return e;
+    const size_t bytes = ((size_t)g.V + 8) * 8;
+    if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mv_fit_segment_kernel, dim3(1), dim3(kMvThreads), bytes, st, g, mem, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st)
+{
+    hipError_t e = mv_set_lds_attr();
+    if (e != hipSuccess) return e;
+    const size_t bytes = mv_lds_bytes(g.V);
+    if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mv_chain_init_kernel, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream_t st)
+{
+    hipError_t e = mv_set_lds_attr();
+    if (e != hipSuccess) return e;
+    const size_t bytes = mv_lds_bytes(g.V);
+    if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mv_chain_run_kernel, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a);
+    return hipGetLastError();
+}
+
+}  // namespace mc

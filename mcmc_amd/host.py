@@ -88,6 +88,23 @@ def load():
         "mcmc_chains_get_profile": (i, [vp, vp]),
         "mcmc_selftest_math": (i, [vp, vp, vp, i, vp, vp, vp]),
         "mcmc_selftest_philox": (i, [vp, vp, vp, vp]),
+        "mcmc_mv_create": (i, [i, C.POINTER(vp)]),
+        "mcmc_mv_destroy": (i, [vp]),
+        "mcmc_mv_last_error": (C.c_char_p, [vp]),
+        "mcmc_mv_synchronize": (i, [vp]),
+        "mcmc_mv_set_graph": (i, [vp, i, vp, vp, vp, vp, vp, u32]),
+        "mcmc_mv_vertex_moments": (i, [vp]),
+        "mcmc_mv_get_vertex_moments": (i, [vp, vp]),
+        "mcmc_mv_fit_segment": (i, [vp, vp, i, vp, C.POINTER(dbl), C.POINTER(dbl)]),
+        "mcmc_mv_pmerge": (i, [vp, vp, vp, vp, i, i, dbl, vp]),
+        "mcmc_mv_chains_init": (i, [vp, i, u32, u32, i, dbl]),
+        "mcmc_mv_chains_run": (i, [vp, u64]),
+        "mcmc_mv_chains_set_trace": (i, [vp, u64]),
+        "mcmc_mv_chains_get_trace": (i, [vp, vp, vp]),
+        "mcmc_mv_chains_get_labels": (i, [vp, i, vp]),
+        "mcmc_mv_chains_get_scalars": (i, [vp] + [vp] * 6),
+        "mcmc_mv_chains_get_planes": (i, [vp, i, vp]),
+        "mcmc_mv_last_run_ms": (dbl, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -279,3 +296,102 @@ def load_scene(ctx: Context, frame: int, scene):
     """Upload one mcmc_amd.scene.Scene and its adjacency into `frame`."""
     ctx.frame_upload(frame, scene.disp, scene.label, scene.n_superpixels)
     ctx.frame_set_graph(frame, scene.row_ptr, scene.col)
+
+
+class Multiview:
+    """Path B: an SPGraph resident in HBM plus chains over it (mcmc_mv_* of include/mcmc_amd.h)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.mcmc_mv_create(device, C.byref(self.h))
+        if rc != 0:
+            raise McmcError(rc, "mcmc_mv_create failed (no GPU?)")
+        self.V = 0
+        self.n_chains = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise McmcError(rc, self.L.mcmc_mv_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.mcmc_mv_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_graph(self, pt_ptr, points, row_ptr, col, q):
+        pt_ptr = np.ascontiguousarray(pt_ptr, np.uint32); points = np.ascontiguousarray(points, np.float32)
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint32); col = np.ascontiguousarray(col, np.uint32)
+        q = np.ascontiguousarray(q, np.float64)
+        assert points.ndim == 2 and points.shape[1] == 4
+        V = pt_ptr.size - 1
+        self._ck(self.L.mcmc_mv_set_graph(self.h, V, _ptr(pt_ptr, np.uint32), _ptr(points, np.float32),
+                                          _ptr(row_ptr, np.uint32), _ptr(col, np.uint32), _ptr(q, np.float64),
+                                          col.size))
+        self.V = V
+        self._ck(self.L.mcmc_mv_vertex_moments(self.h))
+
+    def vertex_moments(self):
+        out = np.zeros((self.V, 10))
+        self._ck(self.L.mcmc_mv_get_vertex_moments(self.h, _ptr(out, np.float64)))
+        return out
+
+    def fit_segment(self, members):
+        m = np.ascontiguousarray(members, np.uint32)
+        pl = np.zeros(5); p = C.c_double(); e = C.c_double()
+        self._ck(self.L.mcmc_mv_fit_segment(self.h, _ptr(m, np.uint32), m.size, _ptr(pl, np.float64),
+                                            C.byref(p), C.byref(e)))
+        return pl, p.value, e.value
+
+    def pmerge(self, t1, t2, w, temperature=8.0):
+        t1 = np.ascontiguousarray(t1, np.float32); t2 = np.ascontiguousarray(t2, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        n, dim = t1.shape
+        out = np.zeros(n)
+        self._ck(self.L.mcmc_mv_pmerge(self.h, _ptr(t1, np.float32), _ptr(t2, np.float32), _ptr(w, np.float32),
+                                       dim, n, temperature, _ptr(out, np.float64)))
+        return out
+
+    def chains_init(self, n_chains, seed=1, chain_offset=0, max_new_segments=1024, split_prob=0.10):
+        self._ck(self.L.mcmc_mv_chains_init(self.h, n_chains, seed, chain_offset, max_new_segments, split_prob))
+        self.n_chains = n_chains
+
+    def chains_set_trace(self, cap):
+        self._ck(self.L.mcmc_mv_chains_set_trace(self.h, cap))
+
+    def chains_run(self, steps, sync=True):
+        self._ck(self.L.mcmc_mv_chains_run(self.h, steps))
+        self._last_steps = steps
+        if sync:
+            self._ck(self.L.mcmc_mv_synchronize(self.h))
+
+    def trace(self):
+        f = np.zeros((self.n_chains, self._last_steps), np.uint8); a = np.zeros((self.n_chains, self._last_steps))
+        self._ck(self.L.mcmc_mv_chains_get_trace(self.h, _ptr(f, np.uint8), _ptr(a, np.float64)))
+        return f, a
+
+    def labels(self, which=0):
+        out = np.zeros((self.n_chains, self.V), np.uint32)
+        self._ck(self.L.mcmc_mv_chains_get_labels(self.h, which, _ptr(out, np.uint32)))
+        return out
+
+    def scalars(self):
+        n = self.n_chains
+        d = dict(n_accept=np.zeros(n, np.uint64), n_split=np.zeros(n, np.uint64), n_skip=np.zeros(n, np.uint64),
+                 trace_hash=np.zeros(n, np.uint64), n_segments=np.zeros(n, np.int32), status=np.zeros(n, np.int32))
+        self._ck(self.L.mcmc_mv_chains_get_scalars(self.h, *[v.ctypes.data_as(C.c_void_p) for v in d.values()]))
+        return d
+
+    def planes(self, chain, n_segments):
+        out = np.zeros((n_segments, 5))
+        self._ck(self.L.mcmc_mv_chains_get_planes(self.h, chain, _ptr(out, np.float64)))
+        return out
+
+    def last_run_ms(self):
+        return float(self.L.mcmc_mv_last_run_ms(self.h))

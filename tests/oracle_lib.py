@@ -62,6 +62,20 @@ def lib():
     L.orc_mix64.restype = C.c_uint64; L.orc_mix64.argtypes = [C.c_uint64]
     L.orc_wave_sum.restype = C.c_double; L.orc_wave_sum.argtypes = [f64p]
     L.orc_wave_prod.restype = C.c_double; L.orc_wave_prod.argtypes = [f64p]
+    L.orc_det_sqrt.restype = C.c_double; L.orc_det_sqrt.argtypes = [C.c_double]
+    L.orc_mv_vertex_moments.argtypes = [f32p, u32p, C.c_int, f64p]
+    L.orc_mv_fit_segment.argtypes = [C.c_int, f32p, u32p, f64p, u32p, C.c_int, f64p,
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_mv_pmerge.restype = C.c_double
+    L.orc_mv_pmerge.argtypes = [f32p, f32p, f32p, C.c_int, C.c_double]
+    L.orc_mv_chains_create.restype = C.c_void_p
+    L.orc_mv_chains_create.argtypes = [C.c_int, f32p, u32p, f64p, u32p, u32p, f64p, C.c_int, C.c_uint32,
+                                       C.c_uint32, C.c_int, C.c_double]
+    L.orc_mv_chains_free.argtypes = [C.c_void_p]
+    L.orc_mv_chains_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.orc_mv_chains_get_labels.argtypes = [C.c_void_p, C.c_int, u32p]
+    L.orc_mv_chains_get_scalars.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.orc_mv_chains_get_planes.argtypes = [C.c_void_p, C.c_int, f64p]
     _lib = L
     return L
 
@@ -157,5 +171,70 @@ class Chains:
     def __del__(self):
         try:
             lib().orc_chains_free(self.h)
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- Path B
+def mv_vertex_moments(points, pt_ptr):
+    V = pt_ptr.size - 1
+    out = np.zeros((V, 10))
+    lib().orc_mv_vertex_moments(np.ascontiguousarray(points, np.float32), np.ascontiguousarray(pt_ptr, np.uint32), V, out)
+    return out
+
+
+def mv_fit_segment(points, pt_ptr, vm, members):
+    V = pt_ptr.size - 1
+    pl = np.zeros(5); p = C.c_double(); e = C.c_double()
+    m = np.ascontiguousarray(members, np.uint32)
+    st = lib().orc_mv_fit_segment(V, np.ascontiguousarray(points, np.float32), np.ascontiguousarray(pt_ptr, np.uint32),
+                                  np.ascontiguousarray(vm), m, m.size, pl, C.byref(p), C.byref(e))
+    assert st == 0
+    return pl, p.value, e.value
+
+
+def mv_pmerge(t1, t2, w, temperature=8.0):
+    t1 = np.ascontiguousarray(t1, np.float32); t2 = np.ascontiguousarray(t2, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    return lib().orc_mv_pmerge(t1, t2, w, t1.size, temperature)
+
+
+class MvChains:
+    """Oracle Path-B sampler (mirrors mcmc_amd.host.Multiview)."""
+
+    def __init__(self, mv, n_chains, seed, chain_offset=0, max_new_segments=1024, split_prob=0.10):
+        self.V = mv.n_vertices; self.n = n_chains
+        self._keep = [np.ascontiguousarray(mv.points, np.float32), np.ascontiguousarray(mv.pt_ptr, np.uint32), None,
+                      np.ascontiguousarray(mv.row_ptr, np.uint32), np.ascontiguousarray(mv.col, np.uint32),
+                      np.ascontiguousarray(mv.q, np.float64)]
+        self._keep[2] = mv_vertex_moments(self._keep[0], self._keep[1])
+        self.h = lib().orc_mv_chains_create(self.V, *self._keep, n_chains, seed, chain_offset, max_new_segments,
+                                            split_prob)
+
+    def run(self, steps):
+        f = np.zeros((self.n, steps), np.uint8); a = np.zeros((self.n, steps))
+        lib().orc_mv_chains_run(self.h, steps, f.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p))
+        return f, a
+
+    def labels(self, which=0):
+        out = np.zeros((self.n, self.V), np.uint32)
+        lib().orc_mv_chains_get_labels(self.h, which, out)
+        return out
+
+    def scalars(self):
+        n = self.n
+        d = dict(n_accept=np.zeros(n, np.uint64), n_split=np.zeros(n, np.uint64), n_skip=np.zeros(n, np.uint64),
+                 trace_hash=np.zeros(n, np.uint64), n_segments=np.zeros(n, np.int32), status=np.zeros(n, np.int32))
+        lib().orc_mv_chains_get_scalars(self.h, *[v.ctypes.data_as(C.c_void_p) for v in d.values()])
+        return d
+
+    def planes(self, chain, n_segments):
+        out = np.zeros((n_segments, 5))
+        lib().orc_mv_chains_get_planes(self.h, chain, out)
+        return out
+
+    def __del__(self):
+        try:
+            lib().orc_mv_chains_free(self.h)
         except Exception:
             pass

@@ -1,0 +1,227 @@
+"""Path B (multiview) tests: SURVEY.md section 8a rows B1-B4.
+
+CPU part: oracle/multiview_oracle.c against what pins it -- numpy's f64 SVD of the
+centred cloud (the formula of MathUtils::fitPlaneSVD, MathUtils.cpp:22-54), the
+reference's own property tests (TestMathUtils.cpp:44-60, TestGraphUtils.cpp:55-71),
+and invariants of the restated loop.  The sampler trajectory itself is "parity
+unpinned" (the reference seeds from time()).
+GPU part (-m gpu): the HIP path through the C ABI, bit-exact against the oracle.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from mcmc_amd.scene import DEFAULT_WEIGHTS, make_multiview, pmerge_np
+from tests import oracle_lib as O
+
+REL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def mv_small():
+    return make_multiview(n_views=3, width=96, height=72, n_planes=3, n_superpixels=24, seed=5)
+
+
+def _numpy_fit(points_list):
+    """fitPlaneSVD + computeProbability in numpy f64, literally (MathUtils.cpp:22-54,
+    SPGraph.cpp:89-104, MultiviewSegment.cpp:71-96)."""
+    cloud = np.concatenate(points_list, axis=0).astype(np.float64)[:, :3].T   # 3 x N
+    centroid = cloud.mean(axis=1)
+    U, S, _ = np.linalg.svd(cloud - centroid[:, None], full_matrices=True)
+    n = U[:, 2]
+    d = n @ centroid
+    cov = U @ np.diag(S * S) @ U.T / 2
+    err = sum(np.abs(p.astype(np.float64)[:, :3] @ n + d).mean() for p in points_list)
+    prob = math.exp(-err / 2.0) * math.sqrt(2.0 * math.pi * np.linalg.det(cov))
+    return n, d, np.linalg.det(cov), err, prob
+
+
+def test_det_sqrt_against_libm():
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([np.exp(rng.uniform(-700, 700, 3000)), rng.uniform(0.25, 4.0, 3000),
+                         [1.0, 2.0, 4.0, 0.25, 1e-310, 5e-324, 1.7976931348623157e308, 0.0]])
+    for x in xs:
+        got, want = O.lib().orc_det_sqrt(float(x)), math.sqrt(x)
+        assert abs(got - want) <= 2.3e-16 * want, (x, got, want)
+    assert math.isnan(O.lib().orc_det_sqrt(-1.0)) and O.lib().orc_det_sqrt(math.inf) == math.inf
+
+
+def test_plane_svd_reference_property():
+    # TestMathUtils.cpp:44-60: noisy plane rotated 45 degrees about x, r = 1, step 0.1, sigma 0.01
+    rng = np.random.default_rng(3)
+    g = np.arange(-1.0, 1.0 + 1e-6, 0.1, dtype=np.float32)
+    x, y = np.meshgrid(g, g, indexing="ij")
+    P = np.stack([x.ravel(), y.ravel(), np.zeros(x.size, np.float32)], axis=1) + rng.normal(0, 0.01, (x.size, 3))
+    c, s = math.cos(math.pi / 4), math.sin(math.pi / 4)
+    R = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    P = (P @ R.T).astype(np.float32)
+    pts = np.concatenate([P, np.ones((P.shape[0], 1), np.float32)], axis=1)
+    pt_ptr = np.array([0, pts.shape[0]], np.uint32)
+    vm = O.mv_vertex_moments(pts, pt_ptr)
+    pl, prob, err = O.mv_fit_segment(pts, pt_ptr, vm, [0])
+    assert abs(np.linalg.norm(pl[:4]) - 1.0) < 1e-5          # CPPUNIT_ASSERT :57 (4-vector norm, d ~ 0)
+    assert abs(pl[:3] @ R[:, 2]) > 0.9                        # :58
+    n, d, det, e_np, p_np = _numpy_fit([pts])
+    sgn = np.sign(n @ pl[:3])
+    assert np.allclose(pl[:3], sgn * n, atol=1e-9) and abs(pl[3] - sgn * d) < 1e-9
+    assert abs(pl[4] - det) <= REL * det and abs(err - e_np) <= REL * e_np and abs(prob - p_np) <= REL * p_np
+
+
+def test_segment_fit_against_numpy_svd(mv_small):
+    mv = mv_small
+    vm = O.mv_vertex_moments(mv.points, mv.pt_ptr)
+    # per-vertex moments are plain sums
+    for v in (0, 5, mv.n_vertices - 1):
+        P = mv.points[mv.pt_ptr[v]:mv.pt_ptr[v + 1], :3].astype(np.float64)
+        want = [P.shape[0], *P.sum(0), (P[:, 0] ** 2).sum(), (P[:, 0] * P[:, 1]).sum(), (P[:, 0] * P[:, 2]).sum(),
+                (P[:, 1] ** 2).sum(), (P[:, 1] * P[:, 2]).sum(), (P[:, 2] ** 2).sum()]
+        assert np.allclose(vm[v], want, rtol=1e-12)
+    rng = np.random.default_rng(0)
+    sets = [[0], [1, 2], list(range(0, mv.n_vertices, 3)),
+            list(np.flatnonzero(mv.plane_of_vertex == 0)), list(range(mv.n_vertices))]
+    sets += [sorted(rng.choice(mv.n_vertices, 6, replace=False).tolist()) for _ in range(4)]
+    for ms in sets:
+        pl, prob, err = O.mv_fit_segment(mv.points, mv.pt_ptr, vm, ms)
+        n, d, det, e_np, p_np = _numpy_fit([mv.points[mv.pt_ptr[v]:mv.pt_ptr[v + 1]] for v in ms])
+        sgn = np.sign(n @ pl[:3])
+        assert abs(np.linalg.norm(pl[:3]) - 1.0) < 1e-12
+        assert np.allclose(pl[:3], sgn * n, atol=1e-7), (ms, pl, n)
+        assert abs(pl[3] - sgn * d) <= 1e-7
+        assert abs(pl[4] - det) <= REL * abs(det)
+        assert abs(err - e_np) <= REL * e_np
+        assert abs(prob - p_np) <= REL * p_np + 1e-300
+
+
+def test_pmerge_reference_properties():
+    # TestGraphUtils.cpp:55-71
+    rng = np.random.default_rng(2)
+    a = rng.uniform(-1, 1, 50).astype(np.float32)
+    w = np.ones(50, np.float32)
+    assert O.mv_pmerge(a, a, w) > 0.999999
+    b = rng.uniform(-1, 1, 50).astype(np.float32)
+    assert O.mv_pmerge(a, b, w) == O.mv_pmerge(b, a, w)
+    t1 = rng.uniform(-1, 1, (20, 7)).astype(np.float32); t2 = t1 + rng.normal(0, 0.05, (20, 7)).astype(np.float32)
+    want = pmerge_np(t1, t2)
+    got = np.array([O.mv_pmerge(t1[i], t2[i], DEFAULT_WEIGHTS) for i in range(20)])
+    assert np.allclose(got, want, rtol=1e-12)
+
+
+def test_oracle_loop_invariants(mv_small):
+    mv = mv_small
+    ch = O.MvChains(mv, 4, seed=3)
+    cur0 = ch.labels(0).copy()
+    # initial partition: connected components numbered by smallest vertex, every edge inside
+    # a component is allowed to be off, but no on-edge may cross components: ids are dense
+    for k in range(4):
+        ids = cur0[k]
+        first = [int(np.flatnonzero(ids == s)[0]) for s in range(ids.max() + 1)]
+        assert first == sorted(first)
+    f, a = ch.run(60)
+    s = ch.scalars()
+    assert (s["status"] == 0).all()
+    assert np.array_equal(ch.labels(0), cur0)                     # currentSegmentID is never updated
+    assert (s["n_segments"] == cur0.max(axis=1) + 1 + s["n_split"]).all()   # every split appends a segment
+    assert (s["n_accept"] == (f & 1).sum(axis=1)).all() and (s["n_split"] == ((f >> 1) & 1).sum(axis=1)).all()
+    assert ((f & 4) == 0).all() or (a[(f & 4) != 0] == 0).all()
+    # a split proposal leaves SB2 == SA2, so a == P(SB1)/P(SA1); all ratios finite or nan, never negative
+    assert (np.isnan(a) | (a >= 0)).all()
+    # determinism, chain offset, continuation
+    ch2 = O.MvChains(mv, 2, seed=3, chain_offset=2)
+    f2, a2 = ch2.run(60)
+    assert np.array_equal(f2, f[2:]) and np.array_equal(a2.view(np.uint64), a[2:].view(np.uint64))
+    ch3 = O.MvChains(mv, 4, seed=3)
+    ch3.run(25); ch3.run(35)
+    assert np.array_equal(ch3.scalars()["trace_hash"], s["trace_hash"])
+    assert np.array_equal(ch3.labels(1), ch.labels(1))
+    # the vertex sets stay a partition whose new segments are exactly the split components
+    own = ch.labels(1)
+    for k in range(4):
+        assert own[k].max() < s["n_segments"][k]
+
+
+def test_capacity_overflow_freezes_chain(mv_small):
+    ch = O.MvChains(mv_small, 2, seed=1, max_new_segments=1, split_prob=1.0)
+    f, _ = ch.run(5)
+    assert (f[:, 0] & 2).all() and (f[:, 1:] == 0xFF).all()
+    assert (ch.scalars()["status"] == -6).all()
+
+
+# ------------------------------------------------------------------ GPU parity
+@pytest.fixture(scope="module")
+def gpu_mv():
+    from mcmc_amd import host
+    m = host.Multiview(device=0)
+    yield m
+    m.close()
+
+
+def _load(gm, mv):
+    gm.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, mv.q)
+
+
+@pytest.mark.gpu
+def test_gpu_vertex_moments_and_fit_bit_exact(gpu_mv, mv_small):
+    mv = mv_small
+    _load(gpu_mv, mv)
+    vm = O.mv_vertex_moments(mv.points, mv.pt_ptr)
+    assert np.array_equal(gpu_mv.vertex_moments().view(np.uint64), vm.view(np.uint64))
+    rng = np.random.default_rng(4)
+    sets = [[0], [3, 4], list(range(mv.n_vertices))] + [sorted(rng.choice(mv.n_vertices, 9, replace=False).tolist())
+                                                         for _ in range(5)]
+    for ms in sets:
+        pl, prob, err = gpu_mv.fit_segment(ms)
+        opl, oprob, oerr = O.mv_fit_segment(mv.points, mv.pt_ptr, vm, ms)
+        assert np.array_equal(pl.view(np.uint64), opl.view(np.uint64)), (ms, pl, opl)
+        assert np.float64(prob).view(np.uint64) == np.float64(oprob).view(np.uint64)
+        assert np.float64(err).view(np.uint64) == np.float64(oerr).view(np.uint64)
+
+
+@pytest.mark.gpu
+def test_gpu_pmerge_bit_exact(gpu_mv):
+    rng = np.random.default_rng(6)
+    t1 = rng.uniform(-1, 1, (300, 7)).astype(np.float32); t2 = t1 + rng.normal(0, 0.1, (300, 7)).astype(np.float32)
+    got = gpu_mv.pmerge(t1, t2, DEFAULT_WEIGHTS)
+    want = np.array([O.mv_pmerge(t1[i], t2[i], DEFAULT_WEIGHTS) for i in range(300)])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(gpu_mv.pmerge(t1, t1, DEFAULT_WEIGHTS), np.ones(300))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split_prob", [0.10, 0.5])
+def test_gpu_chains_bit_exact(gpu_mv, mv_small, split_prob):
+    mv = mv_small
+    _load(gpu_mv, mv)
+    n, steps = 6, 80
+    gpu_mv.chains_init(n, seed=9, chain_offset=3, max_new_segments=64, split_prob=split_prob)
+    gpu_mv.chains_set_trace(steps)
+    orc = O.MvChains(mv, n, seed=9, chain_offset=3, max_new_segments=64, split_prob=split_prob)
+    assert np.array_equal(gpu_mv.labels(0), orc.labels(0))       # initial partition
+    s0 = gpu_mv.scalars()
+    for k in range(n):
+        assert np.array_equal(gpu_mv.planes(k, s0["n_segments"][k]).view(np.uint64),
+                              orc.planes(k, s0["n_segments"][k]).view(np.uint64))
+    gpu_mv.chains_run(steps)
+    of, oa = orc.run(steps)
+    gf, ga = gpu_mv.trace()
+    assert np.array_equal(gf, of)                                 # accept / split / skip sequence
+    assert np.array_equal(ga.view(np.uint64), oa.view(np.uint64)) # ratios bit for bit
+    gs, os_ = gpu_mv.scalars(), orc.scalars()
+    for key in gs:
+        assert np.array_equal(gs[key], os_[key]), key
+    assert np.array_equal(gpu_mv.labels(1), orc.labels(1))
+    # a second launch continues the chains
+    gpu_mv.chains_run(steps)
+    orc.run(steps)
+    assert np.array_equal(gpu_mv.scalars()["trace_hash"], orc.scalars()["trace_hash"])
+
+
+@pytest.mark.gpu
+def test_gpu_chains_capacity_overflow(gpu_mv, mv_small):
+    _load(gpu_mv, mv_small)
+    gpu_mv.chains_init(2, seed=1, max_new_segments=1, split_prob=1.0)
+    gpu_mv.chains_set_trace(5)
+    gpu_mv.chains_run(5)
+    f, _ = gpu_mv.trace()
+    assert (f[:, 0] & 2).all() and (f[:, 1:] == 0xFF).all()
+    assert (gpu_mv.scalars()["status"] == -6).all()
