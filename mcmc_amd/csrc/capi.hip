@@ -63,7 +63,7 @@ struct mcmc_ctx {
     bool ev_valid[K_COUNT]{};
     int chain_variant = 0;
     // tuning overrides (0 / -1 = automatic)
-    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0;
+    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k1_version = 0;
     unsigned long long* d_prof = nullptr;
 };
 
@@ -226,6 +226,7 @@ int mcmc_ctx_set_option(mcmc_ctx* c, const char* name, int value)
     else if (n == "k1_use_lds") c->opt_k1_lds = value;
     else if (n == "k1_debug") c->opt_k1_debug = value;
     else if (n == "k3_profile") c->opt_k3_prof = value;
+    else if (n == "k1_version") c->opt_k1_version = value;
     else return fail(c, MCMC_E_BADARG, "set_option: unknown option " + n);
     return MCMC_OK;
 }
@@ -338,29 +339,47 @@ int mcmc_frames_moments(mcmc_ctx* c, int first, int count)
     MomentArgs a{};
     a.disp = c->d_disp; a.label = c->d_label; a.S = c->d_S; a.mom = c->d_mom;
     a.frame_stride = c->px; a.W = W; a.H = H; a.s_max = c->s_max; a.first_frame = first;
-    bool generic = (W % 8) != 0;
-    int threads = 256;
-    if (!generic) {
-        const int g = W / 8;  // 16-byte chunks per row
+    const bool generic = (W % 8) != 0 || W / 8 > 1024;
+    int threads = 256, bands = 1, mode = 2;
+    size_t lds = 0;
+    if (generic) {
+        bands = std::min(H, std::max(std::max(1, 256 / count), 64));
+    } else if (c->opt_k1_version == 2) {
+        // first-generation kernel (two slots with complement), kept for A/B measurements
+        const int g = W / 8;
         if (g <= 512) { int k = std::max(1, 480 / g); threads = g * k; }
         threads = std::min(threads, 512);
-    }
-    if (c->opt_k1_threads > 0 && !generic) threads = std::min(512, c->opt_k1_threads);
-    // LDS: one int64[S][10] table per workgroup + a 6 KB eviction log per wave
-    int mode = generic ? 2 : 0;
-    size_t lds = 0;
-    if (!generic) {
+        if (c->opt_k1_threads > 0) threads = std::min(512, c->opt_k1_threads);
+        mode = 0;
         lds = moments_lds_bytes(s_used, threads);
-        if (lds > 96 * 1024 || c->opt_k1_lds == 0) { mode = 1; lds = moments_lds_bytes(0, threads); }  // table stays in HBM
+        if (lds > 96 * 1024 || c->opt_k1_lds == 0) { mode = 1; lds = moments_lds_bytes(0, threads); }
+        bands = std::max(1, 256 / count);
+        bands = std::min(bands, std::max(1, H / 32));
+        if (c->opt_k1_bands > 0) bands = std::min(c->opt_k1_bands, H);
+    } else {
+        // left/right kernel: a workgroup is nsub sub-bands x G column strips, every strip at most
+        // 128 rows (32-bit strip-local sums); about one workgroup per CU or more
+        const int G = W / 8;
+        const int nsub_max = std::max(1, (c->opt_k1_threads > 0 ? std::min(1024, c->opt_k1_threads) : 1024) / G);
+        bands = std::max(1, (256 + count - 1) / count);
+        bands = std::min(bands, std::max(1, H / 8));
+        if (c->opt_k1_bands > 0) bands = std::min(c->opt_k1_bands, H);
+        int nsub = nsub_max;
+        for (;;) {
+            const int rpb = (H + bands - 1) / bands;
+            nsub = std::min(nsub_max, std::max(1, rpb / 4));
+            if ((rpb + nsub - 1) / nsub <= 128) break;
+            bands++;
+        }
+        threads = G * nsub;
+        mode = 3;
+        lds = moments_lr_lds_bytes(s_used, threads);
+        if (lds > 160 * 1024 - 64 || c->opt_k1_lds == 0) { mode = 4; lds = moments_lr_lds_bytes(0, threads); }
     }
-    int bands = std::max(1, 256 / count);   // about one workgroup per CU; more only splits the LDS tables
-    bands = std::min(bands, std::max(1, H / 32));
-    if (mode == 2) bands = std::min(H, std::max(bands, 64));
-    if (c->opt_k1_bands > 0) bands = std::min(c->opt_k1_bands, H);
     a.bands = bands;
     a.table_rows = s_used;
     a.debug = c->opt_k1_debug;
-    if (bands > 1 || mode != 0)
+    if (bands > 1 || (mode != 0 && mode != 3))
         HIPCHK(c, hipMemsetAsync(c->d_mom + (size_t)first * c->s_max * MCMC_MOMENT_STRIDE, 0,
                                  (size_t)count * c->s_max * MCMC_MOMENT_STRIDE * 8, c->stream));
     {

@@ -388,6 +388,277 @@ __global__ __launch_bounds__(512) void sp_moments_kernel(MomentArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1, left/right form (the measured path).
+//
+// A lane owns one 8-pixel-wide column strip of a sub-band of at most 128 rows and
+// walks down it.  Two register accumulators: L follows the label of the strip's
+// LEFT pixel (pixel 0 of the chunk), R the label of its RIGHT pixel (pixel 7) when
+// that differs.  A superpixel boundary that wanders through the strip therefore
+// never causes a slot shuffle: L and R are only replaced when the left / right
+// label itself changes (about once per 20 rows).  The rare pixels that belong to
+// neither (a third label inside 8 pixels, 2 % of chunks) are not handled in the
+// hot loop at all: the chunk's position goes to a small per-wave queue that is
+// worked off 64 chunks at a time, one chunk per lane.
+//
+// Accumulators are strip-local and 32 bit (k = column 0..7, r = row 0..127 in the
+// sub-band): n, sum k, sum k^2, sum r n, sum r^2 n, sum r k, sum b, sum k b,
+// sum r b; only sum b^2 needs 64 bits.  Everything a pixel contributes is a
+// packed 16-bit multiply or a v_dot2 on two pixels per dword, exactly as they sit
+// in HBM.  Replaced accumulators go to a per-wave LDS log with plain 16-byte
+// stores; the log is applied 32 records at a time, one record per lane, which is
+// where strip-local sums become the int64 frame moments (10 ds_add_u64 per
+// record into the workgroup's table).
+// ---------------------------------------------------------------------------
+constexpr int kRecCap = 64;        // records per wave log (one eviction per lane always fits)
+constexpr int kRecDwords = 12;     // 48 B per record
+constexpr int kQueueCap = 128;     // queued chunk positions per wave
+constexpr uint32_t kFlushL = 0xFFFFFFF1u, kFlushR = 0xFFFFFFF2u;   // never equal to a 16-bit label
+
+struct Acc {
+    uint32_t lab;
+    int32_t n, k1, k2, rn, rrn, rk, b0, bk, rb;
+    uint32_t bb_lo, bb_hi;
+};
+
+MC_D void acc_reset(Acc& s, uint32_t lab)
+{
+    s.lab = lab; s.n = 0; s.k1 = 0; s.k2 = 0; s.rn = 0; s.rrn = 0; s.rk = 0; s.b0 = 0; s.bk = 0; s.rb = 0;
+    s.bb_lo = 0; s.bb_hi = 0;
+}
+
+MC_D int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
+// add the pixels selected by m[] (pairs of 0/1) of one chunk at strip row r (r2 = r*r); returns their count
+MC_D int acc_add_chunk(Acc& s, const uint32_t m[4], const uint32_t dw[4], int r, int r2)
+{
+    const uint32_t b0 = pk_mul_lo_u16(dw[0], m[0]), b1 = pk_mul_lo_u16(dw[1], m[1]);
+    const uint32_t b2 = pk_mul_lo_u16(dw[2], m[2]), b3 = pk_mul_lo_u16(dw[3], m[3]);
+    const int cnt = sdot2((m[0] + m[1]) + (m[2] + m[3]), kOnes, 0);
+    int kr = sdot2(m[0], 0x00010000u, 0);
+    kr = sdot2(m[1], 0x00030002u, kr); kr = sdot2(m[2], 0x00050004u, kr); kr = sdot2(m[3], 0x00070006u, kr);
+    s.k2 = sdot2(m[0], 0x00010000u, s.k2);
+    s.k2 = sdot2(m[1], 0x00090004u, s.k2); s.k2 = sdot2(m[2], 0x00190010u, s.k2); s.k2 = sdot2(m[3], 0x00310024u, s.k2);
+    int br = sdot2(b0, kOnes, 0);
+    br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
+    s.bk = sdot2(b0, 0x00010000u, s.bk);
+    s.bk = sdot2(b1, 0x00030002u, s.bk); s.bk = sdot2(b2, 0x00050004u, s.bk); s.bk = sdot2(b3, 0x00070006u, s.bk);
+    // two squares <= 2^31 fit 32 bits read as unsigned for every int16 value; four may not
+    const uint32_t q0 = (uint32_t)sdot2(b0, b0, 0), q1 = (uint32_t)sdot2(b1, b1, 0);
+    const uint32_t q2 = (uint32_t)sdot2(b2, b2, 0), q3 = (uint32_t)sdot2(b3, b3, 0);
+    const uint64_t bb = (((uint64_t)s.bb_hi << 32) | s.bb_lo) + (((uint64_t)q0 + q1) + ((uint64_t)q2 + q3));
+    s.bb_lo = (uint32_t)bb; s.bb_hi = (uint32_t)(bb >> 32);
+    s.n += cnt; s.k1 += kr; s.b0 += br;
+    s.rn = mad24(r, cnt, s.rn);
+    s.rrn = mad24(r2, cnt, s.rrn);
+    s.rk = mad24(r, kr, s.rk);
+    s.rb = mad24(r, br, s.rb);
+    return cnt;
+}
+
+// strip-local sums -> frame moments, added to the table row of the label.  All products are
+// 24-bit or 32x32->64 (u0 < 2^13, vb < 2^12, n <= 1024, strip of <= 128 rows).
+MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn, int rrn, int rk,
+                     int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S)
+{
+    if (lab >= (uint32_t)S) return;
+    unsigned long long* t = tab + (size_t)lab * kMomStride;
+    const int su = __mul24((int)u0, n) + k1, sv = __mul24((int)vb, n) + rn;
+    const int x = __mul24((int)u0, rn) + rk;
+    atomicAdd(t + 0, (unsigned long long)(long long)n);
+    atomicAdd(t + 1, (unsigned long long)(long long)su);
+    atomicAdd(t + 2, (unsigned long long)(long long)sv);
+    atomicAdd(t + 3, (unsigned long long)((long long)(int)u0 * (long long)(su + k1) + (long long)k2));
+    atomicAdd(t + 4, (unsigned long long)((long long)(int)vb * (long long)su + (long long)x));
+    atomicAdd(t + 5, (unsigned long long)((long long)(int)vb * (long long)(sv + rn) + (long long)rrn));
+    atomicAdd(t + 6, (unsigned long long)(long long)b0);
+    atomicAdd(t + 7, (unsigned long long)((long long)(int)u0 * (long long)b0 + (long long)bk));
+    atomicAdd(t + 8, (unsigned long long)((long long)(int)vb * (long long)b0 + (long long)rb));
+    atomicAdd(t + 9, ((unsigned long long)bb_hi << 32) | bb_lo);
+}
+
+MC_D void rec_write(uint32_t* rec, const Acc& s, uint32_t u0, uint32_t vb)
+{
+    uint4* q = reinterpret_cast<uint4*>(rec);
+    q[0] = make_uint4(s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 16), (uint32_t)s.rn);
+    q[1] = make_uint4((uint32_t)s.rrn, (uint32_t)s.rk, (uint32_t)s.b0, (uint32_t)s.bk);
+    q[2] = make_uint4((uint32_t)s.rb, s.bb_lo, s.bb_hi, 0u);
+}
+
+MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int lane)
+{
+    const int nact = __popcll((unsigned long long)__ballot(true));
+    for (int i = lane; i < cnt; i += nact) {
+        const uint4* q = reinterpret_cast<const uint4*>(wlog + (size_t)i * kRecDwords);
+        const uint4 a = q[0], b = q[1], c = q[2];
+        sums_apply(a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0xFFFFu), (int)(a.z >> 16),
+                   (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S);
+    }
+}
+
+// append the accumulator of every lane with `pred`; at most one record per lane, so a log of 64 always has
+// room after a drain (wave-uniform control flow)
+MC_D void rec_append(uint32_t* wlog, int& cnt, bool pred, const Acc& s, uint32_t u0, uint32_t vb,
+                     unsigned long long* tab, int S, int lane)
+{
+    const uint64_t m = __ballot(pred);
+    const int k = __popcll((unsigned long long)m);
+    if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, lane); cnt = 0; }
+    if (pred) rec_write(wlog + (size_t)(cnt + mbcnt(m)) * kRecDwords, s, u0, vb);
+    cnt += k;
+}
+
+// work off the queued chunks: one chunk per lane; its pixels that match neither the left nor the right
+// label are added to the table directly (runs of one label merged; normally one run per chunk)
+MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const uint4* lpf, int G,
+                        unsigned long long* tab, int S, int lane)
+{
+    const int nact = __popcll((unsigned long long)__ballot(true));
+    for (int base = 0; base < qcnt; base += nact) {
+        const bool act = base + lane < qcnt;
+        const uint32_t ent = act ? wq[base + lane] : 0u;
+        const uint32_t row = ent & 0xFFFFu, g = ent >> 16;     // absolute row of the frame, strip index
+        uint4 l4 = make_uint4(0u, 0u, 0u, 0u), d4 = l4;
+        if (act) { l4 = lpf[(size_t)row * G + g]; d4 = dpf[(size_t)row * G + g]; }
+        const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
+        const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
+        const uint32_t l0 = lw[0] & 0xFFFFu, l7 = lw[3] >> 16;
+        uint32_t clab = kNoLabel;
+        int n = 0, k1 = 0, k2 = 0, b0 = 0, bk = 0;
+        uint64_t bb = 0;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) {
+            const uint32_t lab = (k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu);
+            const int b = (int)(short)((k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu));
+            const bool isrest = act && lab != l0 && lab != l7;
+            const bool emit = isrest && n != 0 && lab != clab;
+            if (__ballot(emit)) {   // a second run of rest pixels in one chunk: rare
+                if (emit) {
+                    sums_apply(clab, g * 8u, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
+                    n = 0; k1 = 0; k2 = 0; b0 = 0; bk = 0; bb = 0;
+                }
+            }
+            if (isrest) {
+                clab = lab; n += 1; k1 += k; k2 += k * k; b0 += b; bk += k * b;
+                bb += (uint64_t)(uint32_t)(b * b);
+            }
+        }
+        if (n != 0) sums_apply(clab, g * 8u, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
+    }
+}
+
+template <bool TABLE_LDS>
+__global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
+{
+    extern __shared__ unsigned long long lds[];
+    const int frame = a.first_frame + (int)blockIdx.y;
+    const int band = (int)blockIdx.x;
+    const int S = a.S[frame];
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int W = a.W, H = a.H, G = W / 8;
+    unsigned long long* gmom = a.mom + (size_t)frame * a.s_max * kMomStride;
+    unsigned long long* tab = TABLE_LDS ? lds : gmom;
+    uint32_t* wbase = reinterpret_cast<uint32_t*>(lds + (TABLE_LDS ? (size_t)a.table_rows * kMomStride : 0)) +
+                      (size_t)wave * (kRecCap * kRecDwords + kQueueCap);
+    uint32_t* wlog = wbase;
+    uint32_t* wq = wbase + kRecCap * kRecDwords;
+
+    if (TABLE_LDS) {
+        for (int i = tid; i < S * kMomStride; i += T) tab[i] = 0ull;
+        __syncthreads();
+    }
+
+    const int rows_per_band = (H + a.bands - 1) / a.bands;
+    const int r0 = band * rows_per_band;
+    const int r1 = min(H, r0 + rows_per_band);
+    // T = nsub * G (host): sub-band p, column strip g
+    const int nsub = T / G, p = tid / G, g = tid % G;
+    const int R = (max(0, r1 - r0) + nsub - 1) / nsub;       // <= 128 (host): 32-bit strip-local sums
+    const int rs = r0 + p * R, re = min(r1, rs + R);
+    const int count = max(0, re - rs);
+    const uint32_t u0 = (uint32_t)g * 8u;
+    const size_t frame_base = ((size_t)frame * a.frame_stride) / 8;   // in uint4 units (W % 8 == 0)
+    const uint4* dpf = reinterpret_cast<const uint4*>(a.disp) + frame_base;
+    const uint4* lpf = reinterpret_cast<const uint4*>(a.label) + frame_base;
+    const uint4* dp = dpf + (size_t)rs * G + g;
+    const uint4* lp = lpf + (size_t)rs * G + g;
+
+    Acc L, Rr;
+    acc_reset(L, kFlushL);
+    acc_reset(Rr, kFlushR);
+    int cnt = 0, qcnt = 0;     // wave-uniform
+
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 d4 = zero4, l4 = zero4, d4n = zero4, l4n = zero4;
+    if (count > 0) { d4 = dp[0]; l4 = lp[0]; }
+    if (count > 1) { d4n = dp[G]; l4n = lp[G]; }
+    int r2 = 0;
+    // R strip rows, then one more pass with no live lane that flushes both accumulators and the queue
+    for (int it = 0; it <= R; ++it) {
+        uint4 d4nn = zero4, l4nn = zero4;
+        if (it + 2 < count) { d4nn = dp[(size_t)(it + 2) * G]; l4nn = lp[(size_t)(it + 2) * G]; }
+        if (__builtin_expect(qcnt > kQueueCap - 64 || (it == R && qcnt > 0), 0)) {
+            queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
+            qcnt = 0;
+        }
+        const bool live = it < count;
+        const bool fin = it == R;
+        const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
+        const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
+        // a lane that is past its strip keeps its labels until the final pass
+        const uint32_t l0 = live ? (lw[0] & 0xFFFFu) : (fin ? kFlushL : L.lab);
+        const uint32_t l7 = live ? (lw[3] >> 16) : (fin ? kFlushR : l0);
+
+        // the left accumulator follows the label of pixel 0
+        const bool evL = l0 != L.lab;
+        if (__ballot(evL)) {
+            rec_append(wlog, cnt, evL && L.n != 0, L, u0, (uint32_t)rs, tab, S, lane);
+            if (evL) acc_reset(L, l0);
+        }
+        // the right accumulator follows the label of pixel 7 while that differs from pixel 0
+        const bool two = l7 != l0;
+        const bool evR = two && l7 != Rr.lab;
+        if (__ballot(evR)) {
+            rec_append(wlog, cnt, evR && Rr.n != 0, Rr, u0, (uint32_t)rs, tab, S, lane);
+            if (evR) acc_reset(Rr, l7);
+        }
+        // dead lanes hold zero labels: the all-ones pattern matches none of their pixels
+        const uint32_t patL = live ? (l0 | (l0 << 16)) : 0xFFFFFFFFu;
+        const uint32_t patR = l7 | (l7 << 16);
+        const uint32_t twoM = (two && live) ? 0xFFFFFFFFu : 0u;
+        uint32_t mL[4], mR[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mL[j] = match01(lw[j], patL);
+            mR[j] = match01(lw[j], patR) & twoM;
+        }
+        const int cL = acc_add_chunk(L, mL, dw, it, r2);
+        const int cR = acc_add_chunk(Rr, mR, dw, it, r2);
+        // pixels in neither: queue the chunk
+        const bool rest = live && (cL + cR != 8);
+        const uint64_t rm = __ballot(rest);
+        if (rm) {
+            if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | ((uint32_t)g << 16);
+            qcnt += __popcll((unsigned long long)rm);
+        }
+        d4 = d4n; l4 = l4n; d4n = d4nn; l4n = l4nn;
+        r2 += 2 * it + 1;
+    }
+    rec_drain(wlog, cnt, tab, S, lane);
+
+    if (!TABLE_LDS) return;
+    __syncthreads();
+    if (a.bands == 1) {
+        for (int i = tid; i < S * kMomStride; i += T) gmom[i] = tab[i];
+    } else {
+        for (int i = tid; i < S * kMomStride; i += T) {
+            unsigned long long x = tab[i];
+            if (x) atomicAdd(gmom + i, x);
+        }
+    }
+}
+
 // Generic fallback for widths that are not a multiple of 8: one pixel per
 // thread-iteration, global atomics per pixel run of one lane.  Correct for any
 // shape; not the measured path.
@@ -575,6 +846,18 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
 {
     // mode 0: LDS table + log, 1: log only (HBM atomics per record), 2: generic (any width)
     dim3 grid(a.bands, n_frames);
+    if (mode == 3 || mode == 4) {
+        static bool attr3 = false;
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            if (e != hipSuccess) return e;
+            attr3 = true;
+        }
+        if (mode == 3) hipLaunchKernelGGL(sp_moments_lr_kernel<true>, grid, dim3(threads), lds_bytes, st, a);
+        else hipLaunchKernelGGL(sp_moments_lr_kernel<false>, grid, dim3(threads), lds_bytes, st, a);
+        return hipGetLastError();
+    }
     if (mode == 2) {
         hipLaunchKernelGGL(sp_moments_generic_kernel, grid, dim3(256), 0, st, a);
     } else if (mode == 0) {
@@ -590,6 +873,11 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
         hipLaunchKernelGGL(sp_moments_kernel<false>, grid, dim3(threads), lds_bytes, st, a);
     }
     return hipGetLastError();
+}
+
+size_t moments_lr_lds_bytes(int table_rows, int threads)
+{
+    return (size_t)table_rows * kMomStride * 8 + (size_t)((threads + 63) / 64) * (kRecCap * kRecDwords + kQueueCap) * 4;
 }
 
 size_t moments_lds_bytes(int table_rows, int threads)

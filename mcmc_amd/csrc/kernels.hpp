@@ -77,6 +77,7 @@ struct ChainArgs {
 
 hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, int mode, hipStream_t st);
 size_t moments_lds_bytes(int table_rows, int threads);
+size_t moments_lr_lds_bytes(int table_rows, int threads);
 hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st);
 hipError_t launch_edge_prob(const EdgeArgs& a, int n_frames, hipStream_t st);
 hipError_t launch_segment_prob(const SegArgs& a, hipStream_t st);

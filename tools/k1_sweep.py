@@ -21,6 +21,7 @@ combos = [tuple(map(int, c.split(":"))) for c in sys.argv[1:]] or [(8, 320, 1, 0
 for combo in combos:
     bands, threads, lds = combo[:3]
     dbg = combo[3] if len(combo) > 3 else 0
+    ctx.set_option("k1_version", combo[4] if len(combo) > 4 else 0)
     ctx.set_option("k1_debug", dbg)
     ctx.set_option("k1_bands", bands); ctx.set_option("k1_threads", threads); ctx.set_option("k1_use_lds", lds)
     for _ in range(3):
