@@ -429,30 +429,44 @@ MC_D void acc_reset(Acc& s, uint32_t lab)
 
 MC_D int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
 
-// add the pixels selected by m[] (pairs of 0/1) of one chunk at strip row r (r2 = r*r); returns their count
-MC_D int acc_add_chunk(Acc& s, const uint32_t m[4], const uint32_t dw[4], int r, int r2)
+MC_D int sdot2z(uint32_t a, uint32_t b)   // dot2 with a zero addend, no register to clear
 {
-    const uint32_t b0 = pk_mul_lo_u16(dw[0], m[0]), b1 = pk_mul_lo_u16(dw[1], m[1]);
-    const uint32_t b2 = pk_mul_lo_u16(dw[2], m[2]), b3 = pk_mul_lo_u16(dw[3], m[3]);
-    const int cnt = sdot2((m[0] + m[1]) + (m[2] + m[3]), kOnes, 0);
-    int kr = sdot2(m[0], 0x00010000u, 0);
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// Add the pixels selected by m[] (pairs of 0/1) of one chunk at strip row r (r2 = r*r); returns their count.
+// keep = 0 restarts the sums first (the accumulator was just logged), keep = ~0 continues them: the restart
+// is folded into the adds so that no lane-dependent branch touches the twelve registers.
+MC_D int acc_add_chunk(Acc& s, uint32_t keep, const uint32_t m[4], const uint32_t bw[4], int r, int r2)
+{
+    const uint32_t b0 = bw[0], b1 = bw[1], b2 = bw[2], b3 = bw[3];   // disparities of the selected pixels, 0 elsewhere
+    const int cnt = sdot2z((m[0] + m[1]) + (m[2] + m[3]), kOnes);
+    int kr = sdot2z(m[0], 0x00010000u);
     kr = sdot2(m[1], 0x00030002u, kr); kr = sdot2(m[2], 0x00050004u, kr); kr = sdot2(m[3], 0x00070006u, kr);
-    s.k2 = sdot2(m[0], 0x00010000u, s.k2);
-    s.k2 = sdot2(m[1], 0x00090004u, s.k2); s.k2 = sdot2(m[2], 0x00190010u, s.k2); s.k2 = sdot2(m[3], 0x00310024u, s.k2);
-    int br = sdot2(b0, kOnes, 0);
+    int k2 = (int)((uint32_t)s.k2 & keep);
+    k2 = sdot2(m[0], 0x00010000u, k2);
+    k2 = sdot2(m[1], 0x00090004u, k2); k2 = sdot2(m[2], 0x00190010u, k2); k2 = sdot2(m[3], 0x00310024u, k2);
+    s.k2 = k2;
+    int br = sdot2z(b0, kOnes);
     br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
-    s.bk = sdot2(b0, 0x00010000u, s.bk);
-    s.bk = sdot2(b1, 0x00030002u, s.bk); s.bk = sdot2(b2, 0x00050004u, s.bk); s.bk = sdot2(b3, 0x00070006u, s.bk);
+    int bk = (int)((uint32_t)s.bk & keep);
+    bk = sdot2(b0, 0x00010000u, bk);
+    bk = sdot2(b1, 0x00030002u, bk); bk = sdot2(b2, 0x00050004u, bk); bk = sdot2(b3, 0x00070006u, bk);
+    s.bk = bk;
     // two squares <= 2^31 fit 32 bits read as unsigned for every int16 value; four may not
-    const uint32_t q0 = (uint32_t)sdot2(b0, b0, 0), q1 = (uint32_t)sdot2(b1, b1, 0);
-    const uint32_t q2 = (uint32_t)sdot2(b2, b2, 0), q3 = (uint32_t)sdot2(b3, b3, 0);
-    const uint64_t bb = (((uint64_t)s.bb_hi << 32) | s.bb_lo) + (((uint64_t)q0 + q1) + ((uint64_t)q2 + q3));
+    const uint32_t q0 = (uint32_t)sdot2z(b0, b0), q1 = (uint32_t)sdot2z(b1, b1);
+    const uint32_t q2 = (uint32_t)sdot2z(b2, b2), q3 = (uint32_t)sdot2z(b3, b3);
+    const uint64_t bb = (((uint64_t)(s.bb_hi & keep) << 32) | (s.bb_lo & keep)) + (((uint64_t)q0 + q1) + ((uint64_t)q2 + q3));
     s.bb_lo = (uint32_t)bb; s.bb_hi = (uint32_t)(bb >> 32);
-    s.n += cnt; s.k1 += kr; s.b0 += br;
-    s.rn = mad24(r, cnt, s.rn);
-    s.rrn = mad24(r2, cnt, s.rrn);
-    s.rk = mad24(r, kr, s.rk);
-    s.rb = mad24(r, br, s.rb);
+    s.n = (int)((uint32_t)s.n & keep) + cnt;
+    s.k1 = (int)((uint32_t)s.k1 & keep) + kr;
+    s.b0 = (int)((uint32_t)s.b0 & keep) + br;
+    s.rn = mad24(r, cnt, (int)((uint32_t)s.rn & keep));
+    s.rrn = mad24(r2, cnt, (int)((uint32_t)s.rrn & keep));
+    s.rk = mad24(r, kr, (int)((uint32_t)s.rk & keep));
+    s.rb = mad24(r, br, (int)((uint32_t)s.rb & keep));
     return cnt;
 }
 
@@ -479,7 +493,7 @@ MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int 
 
 MC_D void rec_write(uint32_t* rec, const Acc& s, uint32_t u0, uint32_t vb)
 {
-    uint4* q = reinterpret_cast<uint4*>(rec);
+    uint4* q = reinterpret_cast<uint4*>(__builtin_assume_aligned(rec, 16));
     q[0] = make_uint4(s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 16), (uint32_t)s.rn);
     q[1] = make_uint4((uint32_t)s.rrn, (uint32_t)s.rk, (uint32_t)s.b0, (uint32_t)s.bk);
     q[2] = make_uint4((uint32_t)s.rb, s.bb_lo, s.bb_hi, 0u);
@@ -489,7 +503,7 @@ MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int 
 {
     const int nact = __popcll((unsigned long long)__ballot(true));
     for (int i = lane; i < cnt; i += nact) {
-        const uint4* q = reinterpret_cast<const uint4*>(wlog + (size_t)i * kRecDwords);
+        const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog + (size_t)i * kRecDwords, 16));
         const uint4 a = q[0], b = q[1], c = q[2];
         sums_apply(a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0xFFFFu), (int)(a.z >> 16),
                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S);
@@ -547,10 +561,23 @@ MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const ui
     }
 }
 
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// hand-issued 16-byte load and counted wait (the registers are tied to the wait so that no use can move above it)
+MC_D void gload16(u32x4v& dst, const void* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+MC_D void wait_vm(u32x4v& a, u32x4v& b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 template <bool TABLE_LDS>
 __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
 {
-    extern __shared__ unsigned long long lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
     const int frame = a.first_frame + (int)blockIdx.y;
     const int band = (int)blockIdx.x;
     const int S = a.S[frame];
@@ -581,60 +608,72 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     const size_t frame_base = ((size_t)frame * a.frame_stride) / 8;   // in uint4 units (W % 8 == 0)
     const uint4* dpf = reinterpret_cast<const uint4*>(a.disp) + frame_base;
     const uint4* lpf = reinterpret_cast<const uint4*>(a.label) + frame_base;
-    const uint4* dp = dpf + (size_t)rs * G + g;
-    const uint4* lp = lpf + (size_t)rs * G + g;
 
     Acc L, Rr;
     acc_reset(L, kFlushL);
     acc_reset(Rr, kFlushR);
     int cnt = 0, qcnt = 0;     // wave-uniform
 
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 d4 = zero4, l4 = zero4, d4n = zero4, l4n = zero4;
-    if (count > 0) { d4 = dp[0]; l4 = lp[0]; }
-    if (count > 1) { d4n = dp[G]; l4n = lp[G]; }
+    // Three register sets hold the rows it, it+1, it+2 of the strip.  The loads are issued by hand and
+    // waited for with counted s_waitcnt (in-order return): a set is reloaded with row it+3 as soon as its
+    // words have been consumed, and a row only waits until all but the four younger loads have landed,
+    // so 4-6 KB per wave stay in flight under the arithmetic.  Every load is issued by every wave (row
+    // index clamped per lane), otherwise the counts would not hold.
+    const int cl = max(count, 1);
+    const size_t safe0 = (size_t)min(rs, H - 1) * G + g;
+    auto load_row = [&](const int j, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
+        const size_t o = safe0 + (size_t)min(j, cl - 1) * G;
+        gload16(d4, dpf + o);
+        gload16(l4, lpf + o);
+    };
+    u32x4v dA = 0, lA = 0, dB = 0, lB = 0, dC = 0, lC = 0;
+    load_row(0, dA, lA);
+    load_row(1, dB, lB);
+    load_row(2, dC, lC);
     int r2 = 0;
-    // R strip rows, then one more pass with no live lane that flushes both accumulators and the queue
-    for (int it = 0; it <= R; ++it) {
-        uint4 d4nn = zero4, l4nn = zero4;
-        if (it + 2 < count) { d4nn = dp[(size_t)(it + 2) * G]; l4nn = lp[(size_t)(it + 2) * G]; }
+    auto row = [&](const int it, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
         if (__builtin_expect(qcnt > kQueueCap - 64 || (it == R && qcnt > 0), 0)) {
             queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
             qcnt = 0;
         }
         const bool live = it < count;
         const bool fin = it == R;
+        // exactly four younger loads (rows it+1, it+2) are in flight: every row issues its reload, the
+        // last ones re-read the strip's last row (cache hits) so that this count never changes
+        wait_vm<4>(d4, l4);
         const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
         const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
         // a lane that is past its strip keeps its labels until the final pass
         const uint32_t l0 = live ? (lw[0] & 0xFFFFu) : (fin ? kFlushL : L.lab);
         const uint32_t l7 = live ? (lw[3] >> 16) : (fin ? kFlushR : l0);
-
-        // the left accumulator follows the label of pixel 0
         const bool evL = l0 != L.lab;
-        if (__ballot(evL)) {
-            rec_append(wlog, cnt, evL && L.n != 0, L, u0, (uint32_t)rs, tab, S, lane);
-            if (evL) acc_reset(L, l0);
-        }
-        // the right accumulator follows the label of pixel 7 while that differs from pixel 0
         const bool two = l7 != l0;
         const bool evR = two && l7 != Rr.lab;
-        if (__ballot(evR)) {
-            rec_append(wlog, cnt, evR && Rr.n != 0, Rr, u0, (uint32_t)rs, tab, S, lane);
-            if (evR) acc_reset(Rr, l7);
-        }
-        // dead lanes hold zero labels: the all-ones pattern matches none of their pixels
-        const uint32_t patL = live ? (l0 | (l0 << 16)) : 0xFFFFFFFFu;
-        const uint32_t patR = l7 | (l7 << 16);
+        // dead lanes match nothing
+        const uint32_t patL = l0 | (l0 << 16), patR = l7 | (l7 << 16);
+        const uint32_t liveM = live ? 0xFFFFFFFFu : 0u;
         const uint32_t twoM = (two && live) ? 0xFFFFFFFFu : 0u;
-        uint32_t mL[4], mR[4];
+        uint32_t mL[4], mR[4], bL[4], bR[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mL[j] = match01(lw[j], patL);
+            mL[j] = match01(lw[j], patL) & liveM;
             mR[j] = match01(lw[j], patR) & twoM;
+            bL[j] = pk_mul_lo_u16(dw[j], mL[j]);
+            bR[j] = pk_mul_lo_u16(dw[j], mR[j]);
         }
-        const int cL = acc_add_chunk(L, mL, dw, it, r2);
-        const int cR = acc_add_chunk(Rr, mR, dw, it, r2);
+        // this set's words are consumed: fetch row it+3 into it
+        load_row(it + 3, d4, l4);
+
+        // the left accumulator follows the label of pixel 0
+        if (__ballot(evL)) rec_append(wlog, cnt, evL && L.n != 0, L, u0, (uint32_t)rs, tab, S, lane);
+        const uint32_t keepL = evL ? 0u : 0xFFFFFFFFu;
+        L.lab = l0;
+        // the right accumulator follows the label of pixel 7 while that differs from pixel 0
+        if (__ballot(evR)) rec_append(wlog, cnt, evR && Rr.n != 0, Rr, u0, (uint32_t)rs, tab, S, lane);
+        const uint32_t keepR = evR ? 0u : 0xFFFFFFFFu;
+        Rr.lab = evR ? l7 : Rr.lab;
+        const int cL = acc_add_chunk(L, keepL, mL, bL, it, r2);
+        const int cR = acc_add_chunk(Rr, keepR, mR, bR, it, r2);
         // pixels in neither: queue the chunk
         const bool rest = live && (cL + cR != 8);
         const uint64_t rm = __ballot(rest);
@@ -642,9 +681,18 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
             if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | ((uint32_t)g << 16);
             qcnt += __popcll((unsigned long long)rm);
         }
-        d4 = d4n; l4 = l4n; d4n = d4nn; l4n = l4nn;
         r2 += 2 * it + 1;
+    };
+    // R strip rows, then one more pass with no live lane that flushes both accumulators and the queue
+    for (int it = 0; it <= R; it += 3) {
+        row(it, dA, lA);
+        if (it + 1 > R) break;
+        row(it + 1, dB, lB);
+        if (it + 2 > R) break;
+        row(it + 2, dC, lC);
     }
+    // the last reloads are never consumed, but their registers must not be reused while they are in flight
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dA), "+v"(lA), "+v"(dB), "+v"(lB), "+v"(dC), "+v"(lC) :: "memory");
     rec_drain(wlog, cnt, tab, S, lane);
 
     if (!TABLE_LDS) return;
