@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512) void sp_moments_kernel(MomentArgs a)
 constexpr int kRecCap = 64;        // records per wave log (one eviction per lane always fits)
 constexpr int kRecDwords = 12;     // 48 B per record
 constexpr int kQueueCap = 128;     // queued chunk positions per wave
-constexpr uint32_t kFlushL = 0xFFFFFFF1u, kFlushR = 0xFFFFFFF2u;   // never equal to a 16-bit label
+constexpr uint32_t kFlushL = 0xFFFEFFFFu, kFlushR = 0xFFFDFFFFu;   // never equal to a 16-bit label; low half 0xFFFF >= S
 
 struct Acc {
     uint32_t lab;
@@ -429,6 +429,13 @@ MC_D void acc_reset(Acc& s, uint32_t lab)
 
 MC_D int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
 
+MC_D int udot4(uint32_t a, uint32_t b, int c) { return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false); }
+MC_D int udot4z(uint32_t a, uint32_t b)
+{
+    int d;
+    asm("v_dot4_u32_u8 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 MC_D int sdot2z(uint32_t a, uint32_t b)   // dot2 with a zero addend, no register to clear
 {
     int d;
@@ -442,13 +449,12 @@ MC_D int sdot2z(uint32_t a, uint32_t b)   // dot2 with a zero addend, no registe
 MC_D int acc_add_chunk(Acc& s, uint32_t keep, const uint32_t m[4], const uint32_t bw[4], int r, int r2)
 {
     const uint32_t b0 = bw[0], b1 = bw[1], b2 = bw[2], b3 = bw[3];   // disparities of the selected pixels, 0 elsewhere
-    const int cnt = sdot2z((m[0] + m[1]) + (m[2] + m[3]), kOnes);
-    int kr = sdot2z(m[0], 0x00010000u);
-    kr = sdot2(m[1], 0x00030002u, kr); kr = sdot2(m[2], 0x00050004u, kr); kr = sdot2(m[3], 0x00070006u, kr);
-    int k2 = (int)((uint32_t)s.k2 & keep);
-    k2 = sdot2(m[0], 0x00010000u, k2);
-    k2 = sdot2(m[1], 0x00090004u, k2); k2 = sdot2(m[2], 0x00190010u, k2); k2 = sdot2(m[3], 0x00310024u, k2);
-    s.k2 = k2;
+    // the eight 0/1 flags as bytes of two dwords: count, sum k and sum k^2 are three v_dot4 pairs
+    const uint32_t p01 = __builtin_amdgcn_perm(m[1], m[0], 0x06040200u);
+    const uint32_t p23 = __builtin_amdgcn_perm(m[3], m[2], 0x06040200u);
+    const int cnt = udot4(p23, 0x01010101u, udot4z(p01, 0x01010101u));
+    const int kr = udot4(p23, 0x07060504u, udot4z(p01, 0x03020100u));
+    s.k2 = udot4(p23, 0x31241910u, udot4(p01, 0x09040100u, (int)((uint32_t)s.k2 & keep)));
     int br = sdot2z(b0, kOnes);
     br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
     int bk = (int)((uint32_t)s.bk & keep);
@@ -491,34 +497,38 @@ MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int 
     atomicAdd(t + 9, ((unsigned long long)bb_hi << 32) | bb_lo);
 }
 
-MC_D void rec_write(uint32_t* rec, const Acc& s, uint32_t u0, uint32_t vb)
+MC_D uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+MC_D void rec_write(uint32_t* wlog, int idx, const Acc& s, uint32_t u0, uint32_t vb)
 {
-    uint4* q = reinterpret_cast<uint4*>(__builtin_assume_aligned(rec, 16));
-    q[0] = make_uint4(s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 16), (uint32_t)s.rn);
-    q[1] = make_uint4((uint32_t)s.rrn, (uint32_t)s.rk, (uint32_t)s.b0, (uint32_t)s.bk);
-    q[2] = make_uint4((uint32_t)s.rb, s.bb_lo, s.bb_hi, 0u);
+    // three 16-byte LDS stores (the record stride and the log base are multiples of 16 bytes)
+    typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4), aligned(16)));
+    __attribute__((address_space(3))) lds_u32x4* q =
+        (__attribute__((address_space(3))) lds_u32x4*)wlog + idx * (kRecDwords / 4);
+    q[0] = lds_u32x4{ s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 16), (uint32_t)s.rn };
+    q[1] = lds_u32x4{ (uint32_t)s.rrn, (uint32_t)s.rk, (uint32_t)s.b0, (uint32_t)s.bk };
+    q[2] = lds_u32x4{ (uint32_t)s.rb, s.bb_lo, s.bb_hi, 0u };
 }
 
 MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int lane)
 {
-    const int nact = __popcll((unsigned long long)__ballot(true));
+    const int nact = __popcll((unsigned long long)ballot64(true));
     for (int i = lane; i < cnt; i += nact) {
-        const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog + (size_t)i * kRecDwords, 16));
+        const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog, 16)) + i * (kRecDwords / 4);
         const uint4 a = q[0], b = q[1], c = q[2];
         sums_apply(a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0xFFFFu), (int)(a.z >> 16),
                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S);
     }
 }
 
-// append the accumulator of every lane with `pred`; at most one record per lane, so a log of 64 always has
-// room after a drain (wave-uniform control flow)
-MC_D void rec_append(uint32_t* wlog, int& cnt, bool pred, const Acc& s, uint32_t u0, uint32_t vb,
+// append the accumulator of every lane in mask m (pred = this lane's bit); at most one record per lane, so a
+// log of 64 always has room after a drain (wave-uniform control flow)
+MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc& s, uint32_t u0, uint32_t vb,
                      unsigned long long* tab, int S, int lane)
 {
-    const uint64_t m = __ballot(pred);
     const int k = __popcll((unsigned long long)m);
     if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, lane); cnt = 0; }
-    if (pred) rec_write(wlog + (size_t)(cnt + mbcnt(m)) * kRecDwords, s, u0, vb);
+    if (pred) rec_write(wlog, cnt + mbcnt(m), s, u0, vb);
     cnt += k;
 }
 
@@ -527,7 +537,7 @@ MC_D void rec_append(uint32_t* wlog, int& cnt, bool pred, const Acc& s, uint32_t
 MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const uint4* lpf, int G,
                         unsigned long long* tab, int S, int lane)
 {
-    const int nact = __popcll((unsigned long long)__ballot(true));
+    const int nact = __popcll((unsigned long long)ballot64(true));
     for (int base = 0; base < qcnt; base += nact) {
         const bool act = base + lane < qcnt;
         const uint32_t ent = act ? wq[base + lane] : 0u;
@@ -546,7 +556,7 @@ MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const ui
             const int b = (int)(short)((k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu));
             const bool isrest = act && lab != l0 && lab != l7;
             const bool emit = isrest && n != 0 && lab != clab;
-            if (__ballot(emit)) {   // a second run of rest pixels in one chunk: rare
+            if (ballot64(emit)) {   // a second run of rest pixels in one chunk: rare
                 if (emit) {
                     sums_apply(clab, g * 8u, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
                     n = 0; k1 = 0; k2 = 0; b0 = 0; bk = 0; bb = 0;
@@ -574,7 +584,13 @@ MC_D void wait_vm(u32x4v& a, u32x4v& b)
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
-template <bool TABLE_LDS>
+// value the optimiser cannot see through: keeps a 0 / ~0 mask a register that is ANDed (a select costs
+// 1.5x an AND on gfx950, and 5x in its VCC form)
+MC_D uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
+
+// RAGGED: some strip of the launch has fewer than R rows (H not a multiple of bands * nsub); lanes past
+// their strip then keep their labels and are masked out.  The common full-strip case pays nothing for it.
+template <bool TABLE_LDS, bool RAGGED>
 __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
@@ -587,7 +603,7 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     unsigned long long* gmom = a.mom + (size_t)frame * a.s_max * kMomStride;
     unsigned long long* tab = TABLE_LDS ? lds : gmom;
     uint32_t* wbase = reinterpret_cast<uint32_t*>(lds + (TABLE_LDS ? (size_t)a.table_rows * kMomStride : 0)) +
-                      (size_t)wave * (kRecCap * kRecDwords + kQueueCap);
+                      wave * (kRecCap * kRecDwords + kQueueCap);
     uint32_t* wlog = wbase;
     uint32_t* wq = wbase + kRecCap * kRecDwords;
 
@@ -603,7 +619,7 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     const int nsub = T / G, p = tid / G, g = tid % G;
     const int R = (max(0, r1 - r0) + nsub - 1) / nsub;       // <= 128 (host): 32-bit strip-local sums
     const int rs = r0 + p * R, re = min(r1, rs + R);
-    const int count = max(0, re - rs);
+    const int count = max(0, re - rs);                        // == R for every lane unless RAGGED
     const uint32_t u0 = (uint32_t)g * 8u;
     const size_t frame_base = ((size_t)frame * a.frame_stride) / 8;   // in uint4 units (W % 8 == 0)
     const uint4* dpf = reinterpret_cast<const uint4*>(a.disp) + frame_base;
@@ -614,85 +630,94 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     acc_reset(Rr, kFlushR);
     int cnt = 0, qcnt = 0;     // wave-uniform
 
-    // Three register sets hold the rows it, it+1, it+2 of the strip.  The loads are issued by hand and
-    // waited for with counted s_waitcnt (in-order return): a set is reloaded with row it+3 as soon as its
-    // words have been consumed, and a row only waits until all but the four younger loads have landed,
-    // so 4-6 KB per wave stay in flight under the arithmetic.  Every load is issued by every wave (row
-    // index clamped per lane), otherwise the counts would not hold.
+    // Four register sets hold the rows it .. it+3 of the strip.  The loads are issued by hand and
+    // waited for with counted s_waitcnt (in-order return): a set is reloaded with row it+4 as soon as its
+    // words have been consumed, and a row only waits until all but the six younger loads have landed,
+    // so 6-8 KB per wave stay in flight under the arithmetic.  Every load is issued by every wave (row
+    // index clamped per lane; the last reloads re-read the strip's last row), otherwise the count of
+    // younger loads would not be the constant the wait relies on.
     const int cl = max(count, 1);
-    const size_t safe0 = (size_t)min(rs, H - 1) * G + g;
+    const uint32_t safe0 = (uint32_t)(min(rs, H - 1) * G + g);          // < 2^21 uint4 per frame
     auto load_row = [&](const int j, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
-        const size_t o = safe0 + (size_t)min(j, cl - 1) * G;
+        const uint32_t o = safe0 + (uint32_t)__mul24(RAGGED ? min(j, cl - 1) : min(j, R - 1), G);
         gload16(d4, dpf + o);
         gload16(l4, lpf + o);
     };
-    u32x4v dA = 0, lA = 0, dB = 0, lB = 0, dC = 0, lC = 0;
+    u32x4v dA = 0, lA = 0, dB = 0, lB = 0, dC = 0, lC = 0, dD = 0, lD = 0;
     load_row(0, dA, lA);
     load_row(1, dB, lB);
     load_row(2, dC, lC);
+    load_row(3, dD, lD);
     int r2 = 0;
     auto row = [&](const int it, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
-        if (__builtin_expect(qcnt > kQueueCap - 64 || (it == R && qcnt > 0), 0)) {
+        if (__builtin_expect(qcnt > kQueueCap - 64, 0)) {
             queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
             qcnt = 0;
         }
-        const bool live = it < count;
-        const bool fin = it == R;
-        // exactly four younger loads (rows it+1, it+2) are in flight: every row issues its reload, the
-        // last ones re-read the strip's last row (cache hits) so that this count never changes
-        wait_vm<4>(d4, l4);
+        wait_vm<6>(d4, l4);
         const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
         const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
-        // a lane that is past its strip keeps its labels until the final pass
-        const uint32_t l0 = live ? (lw[0] & 0xFFFFu) : (fin ? kFlushL : L.lab);
-        const uint32_t l7 = live ? (lw[3] >> 16) : (fin ? kFlushR : l0);
+        const bool live = !RAGGED || it < count;
+        // a lane that is past its strip keeps its labels
+        const uint32_t l0 = live ? (lw[0] & 0xFFFFu) : L.lab;
+        const uint32_t l7 = live ? (lw[3] >> 16) : l0;
         const bool evL = l0 != L.lab;
         const bool two = l7 != l0;
         const bool evR = two && l7 != Rr.lab;
-        // dead lanes match nothing
         const uint32_t patL = l0 | (l0 << 16), patR = l7 | (l7 << 16);
-        const uint32_t liveM = live ? 0xFFFFFFFFu : 0u;
-        const uint32_t twoM = (two && live) ? 0xFFFFFFFFu : 0u;
+        const uint32_t twoM = opaque((two && live) ? 0xFFFFFFFFu : 0u);
+        const uint32_t liveM = RAGGED ? opaque(live ? 0xFFFFFFFFu : 0u) : 0xFFFFFFFFu;
         uint32_t mL[4], mR[4], bL[4], bR[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mL[j] = match01(lw[j], patL) & liveM;
+            mL[j] = match01(lw[j], patL);
+            if (RAGGED) mL[j] &= liveM;
             mR[j] = match01(lw[j], patR) & twoM;
             bL[j] = pk_mul_lo_u16(dw[j], mL[j]);
             bR[j] = pk_mul_lo_u16(dw[j], mR[j]);
         }
-        // this set's words are consumed: fetch row it+3 into it
-        load_row(it + 3, d4, l4);
+        // this set's words are consumed: fetch row it+4 into it
+        load_row(it + 4, d4, l4);
 
         // the left accumulator follows the label of pixel 0
-        if (__ballot(evL)) rec_append(wlog, cnt, evL && L.n != 0, L, u0, (uint32_t)rs, tab, S, lane);
-        const uint32_t keepL = evL ? 0u : 0xFFFFFFFFu;
+        const uint64_t emL = ballot64(evL);   // an accumulator that is still empty logs zeros: harmless
+        if (emL) rec_append(wlog, cnt, emL, evL, L, u0, (uint32_t)rs, tab, S, lane);
+        const uint32_t keepL = opaque(evL ? 0u : 0xFFFFFFFFu);
         L.lab = l0;
         // the right accumulator follows the label of pixel 7 while that differs from pixel 0
-        if (__ballot(evR)) rec_append(wlog, cnt, evR && Rr.n != 0, Rr, u0, (uint32_t)rs, tab, S, lane);
-        const uint32_t keepR = evR ? 0u : 0xFFFFFFFFu;
+        const uint64_t emR = ballot64(evR);
+        if (emR) rec_append(wlog, cnt, emR, evR, Rr, u0, (uint32_t)rs, tab, S, lane);
+        const uint32_t keepR = opaque(evR ? 0u : 0xFFFFFFFFu);
         Rr.lab = evR ? l7 : Rr.lab;
         const int cL = acc_add_chunk(L, keepL, mL, bL, it, r2);
         const int cR = acc_add_chunk(Rr, keepR, mR, bR, it, r2);
         // pixels in neither: queue the chunk
         const bool rest = live && (cL + cR != 8);
-        const uint64_t rm = __ballot(rest);
+        const uint64_t rm = ballot64(rest);
         if (rm) {
             if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | ((uint32_t)g << 16);
             qcnt += __popcll((unsigned long long)rm);
         }
         r2 += 2 * it + 1;
     };
-    // R strip rows, then one more pass with no live lane that flushes both accumulators and the queue
-    for (int it = 0; it <= R; it += 3) {
+    for (int it = 0; it < R; it += 4) {
         row(it, dA, lA);
-        if (it + 1 > R) break;
+        if (it + 1 >= R) break;
         row(it + 1, dB, lB);
-        if (it + 2 > R) break;
+        if (it + 2 >= R) break;
         row(it + 2, dC, lC);
+        if (it + 3 >= R) break;
+        row(it + 3, dD, lD);
     }
     // the last reloads are never consumed, but their registers must not be reused while they are in flight
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dA), "+v"(lA), "+v"(dB), "+v"(lB), "+v"(dC), "+v"(lC) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dA), "+v"(lA), "+v"(dB), "+v"(lB), "+v"(dC), "+v"(lC), "+v"(dD), "+v"(lD) :: "memory");
+    // flush: queued chunks, both accumulators, the log
+    if (qcnt) queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
+    {
+        const bool wl = L.n != 0, wr = Rr.n != 0;
+        rec_append(wlog, cnt, ballot64(wl), wl, L, u0, (uint32_t)rs, tab, S, lane);
+        rec_append(wlog, cnt, ballot64(wr), wr, Rr, u0, (uint32_t)rs, tab, S, lane);
+    }
     rec_drain(wlog, cnt, tab, S, lane);
 
     if (!TABLE_LDS) return;
@@ -897,13 +922,24 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
     if (mode == 3 || mode == 4) {
         static bool attr3 = false;
         if (!attr3) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
             if (e != hipSuccess) return e;
             attr3 = true;
         }
-        if (mode == 3) hipLaunchKernelGGL(sp_moments_lr_kernel<true>, grid, dim3(threads), lds_bytes, st, a);
-        else hipLaunchKernelGGL(sp_moments_lr_kernel<false>, grid, dim3(threads), lds_bytes, st, a);
+        // ragged: some strip has fewer rows than the others
+        const int rpb = (a.H + a.bands - 1) / a.bands, nsub = threads / (a.W / 8);
+        const bool ragged = (a.H % a.bands) != 0 || (rpb % nsub) != 0;
+        if (mode == 3) {
+            if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<true, true>), grid, dim3(threads), lds_bytes, st, a);
+            else hipLaunchKernelGGL((sp_moments_lr_kernel<true, false>), grid, dim3(threads), lds_bytes, st, a);
+        } else {
+            if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<false, true>), grid, dim3(threads), lds_bytes, st, a);
+            else hipLaunchKernelGGL((sp_moments_lr_kernel<false, false>), grid, dim3(threads), lds_bytes, st, a);
+        }
         return hipGetLastError();
     }
     if (mode == 2) {
