@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-multiview", action="store_true")
+    ap.add_argument("--mv-chains", type=int, default=1024)
+    ap.add_argument("--mv-steps", type=int, default=20)
     return ap.parse_args()
 
 
@@ -124,6 +127,27 @@ def k1_roofline(host, sc_list, n_frames, reps, device):
             "launches": reps, "traffic": traffic}
 
 
+def multiview_line(host, device, n_chains, steps):
+    """Path B (BASELINE configs[3], "C4"): 3 synthetic views, ~500 superpixels each, `n_chains` chains x `steps`
+    proposals of the PatternedMatcher loop (the reference runs 20, PatternedMatcher.cpp:29)."""
+    from mcmc_amd.scene import make_multiview
+    mv = make_multiview(n_views=3, width=640, height=480, n_planes=8, n_superpixels=500, seed=4)
+    m = host.Multiview(device=device)
+    m.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, mv.q)
+    m.chains_init(n_chains, seed=4, max_new_segments=4 * steps)
+    m.chains_run(steps)                      # warm-up launch
+    m.chains_run(steps)
+    ms = m.last_run_ms()
+    sc = m.scalars()
+    assert (sc["status"] == 0).all()
+    m.close()
+    return {"workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
+                        % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
+            "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,
+            "accept_rate": float(sc["n_accept"].sum()) / (2.0 * n_chains * steps),
+            "bound": "L2 / Infinity Cache (16 B x points of the four segments per proposal)"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -178,7 +202,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # after the timed region: the only exchange of the multi-GPU path, RCCL when N > 1
+    from mcmc_amd import distributed as D
     sca = ctx.scalars()
+    best_e, best_chain, best_labels, per_rank = D.gather_best(sca["best_energy"], ctx.labels(1, True), rank * a.chains)
+    marg = D.reduce_marginals(ctx.marginals(0), shared_frames=True)
+    n_valid = int((ctx.local_fit(0)[1] != 0).sum())
+    # every valid superpixel is counted once per chain per measured sampler iteration, on every rank
+    assert int(marg.sum()) == world * a.chains * a.iters_per_step * (a.warmup + a.steps) * n_valid
     assert (sca["status"] == 0).all(), "a chain reported an error status"
     total_steps = (a.warmup + a.steps) * a.iters_per_step
     assert (sca["n_case"].sum(axis=1) == total_steps).all()
@@ -194,7 +225,8 @@ def main():
                                % (a.seed, S, a.chains, a.iters_per_step),
                    "chains_per_gpu": a.chains, "iters_per_step": a.iters_per_step, "superpixels": S,
                    "directed_edges": int(sc.col.size), "accept_rate": acc_rate,
-                   "segments_mean": float(np.mean([len(np.unique(l[:S])) for l in ctx.labels(0, True)[:64]]))},
+                   "segments_mean": float(np.mean([len(np.unique(l[:S])) for l in ctx.labels(0, True)[:64]])),
+                   "best_energy": best_e, "best_chain": best_chain, "ranks_gathered": len(per_rank)},
     }
     if rank == 0:
         k3_ms = chain_ms[-1]
@@ -206,6 +238,8 @@ def main():
                                    "local_fit": ctx.last_kernel_ms(host.K_LOCAL_FIT),
                                    "edge_prob": ctx.last_kernel_ms(host.K_EDGE_PROB)}
     ctx.close()
+    if rank == 0 and world == 1 and not a.no_multiview:
+        out["multiview"] = multiview_line(host, local, a.mv_chains, a.mv_steps)
     if rank == 0 and world == 1:
         if not a.no_roofline:
             scs = [sc] + [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=100 + i)

@@ -225,3 +225,24 @@ def test_gpu_chains_capacity_overflow(gpu_mv, mv_small):
     f, _ = gpu_mv.trace()
     assert (f[:, 0] & 2).all() and (f[:, 1:] == 0xFF).all()
     assert (gpu_mv.scalars()["status"] == -6).all()
+
+
+@pytest.mark.gpu
+def test_gpu_chains_c4_size_bit_exact(gpu_mv):
+    # BASELINE configs[3] at full size (3 views x 640x480, ~500 superpixels each), a few chains
+    mv = make_multiview(n_views=3, width=640, height=480, n_planes=8, n_superpixels=500, seed=4)
+    _load(gpu_mv, mv)
+    n, steps = 3, 12
+    gpu_mv.chains_init(n, seed=2, max_new_segments=32)
+    gpu_mv.chains_set_trace(steps)
+    orc = O.MvChains(mv, n, seed=2, max_new_segments=32)
+    assert np.array_equal(gpu_mv.labels(0), orc.labels(0))
+    gpu_mv.chains_run(steps)
+    of, oa = orc.run(steps)
+    gf, ga = gpu_mv.trace()
+    assert np.array_equal(gf, of) and np.array_equal(ga.view(np.uint64), oa.view(np.uint64))
+    assert np.array_equal(gpu_mv.scalars()["trace_hash"], orc.scalars()["trace_hash"])
+    # size-independent property: a split proposal leaves SB2 == SA2, so its ratio is P(SB1)/P(SA1) and the
+    # vertex sets stay a partition
+    own = gpu_mv.labels(1)
+    assert (own.max(axis=1) < gpu_mv.scalars()["n_segments"]).all()
