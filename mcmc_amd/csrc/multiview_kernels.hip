@@ -281,26 +281,36 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int v = tid; v < V; v += kMvThreads) L.cur[v] = 0xFFFFu;
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {
+        // Bernoulli(q) per undirected edge (draw index = rank of the edge, so both directions agree), then
+        // connected components numbered by their smallest vertex.  One wave: 64 out-edges of the popped
+        // vertex per pass; every on-edge to an unlabelled vertex labels and pushes it.
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, 0xFFFFFFFFu, 0xFFFFFFFFu };
         int ncomp = 0;
-        for (int s = 0; s < V; ++s) {
-            if (L.cur[s] != 0xFFFFu) continue;
-            int sp = 0;
-            L.sv[sp++] = (uint16_t)s; L.cur[s] = (uint16_t)ncomp;
+        for (int s0 = 0; s0 < V; ++s0) {
+            if (L.cur[s0] != 0xFFFFu) continue;      // wave-uniform (LDS value)
+            int sp = 1;
+            if (lane == 0) { L.sv[0] = (uint16_t)s0; L.cur[s0] = (uint16_t)ncomp; }
             while (sp) {
-                const int v = L.sv[--sp];
+                const int v = L.sv[sp - 1];
+                sp--;
                 const uint32_t e1 = g.rowp[v + 1];
-                for (uint32_t e = g.rowp[v]; e < e1; ++e) {
-                    const uint32_t j = g.col[e];
-                    if (L.cur[j] != 0xFFFFu) continue;
-                    const double u = mv_unit(mv_draw_at(rg, g.erank[e]));
-                    if (u <= g.q[e]) { L.cur[j] = (uint16_t)ncomp; L.sv[sp++] = (uint16_t)j; }
+                for (uint32_t eb = g.rowp[v]; eb < e1; eb += kWave) {
+                    const uint32_t e = eb + (uint32_t)lane;
+                    bool ok = false;
+                    uint32_t j = 0;
+                    if (e < e1) {
+                        j = g.col[e];
+                        if (L.cur[j] == 0xFFFFu) ok = mv_unit(mv_draw_at(rg, g.erank[e])) <= g.q[e];   // inclusive (:23)
+                    }
+                    const uint64_t m = __ballot(ok);
+                    if (ok) { L.cur[j] = (uint16_t)ncomp; L.sv[sp + mbcnt(m)] = (uint16_t)j; }
+                    sp += __popcll((unsigned long long)m);
                 }
             }
             ncomp++;
         }
-        L.sh->nn = ncomp;
+        if (lane == 0) L.sh->nn = ncomp;
     }
     __syncthreads();
     const int nseg = L.sh->nn;
@@ -349,35 +359,58 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             continue;
         }
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
-        // ---- phase 1a (serial): start vertex, DFS growth, move type ----
-        if (tid == 0) {
+        // ---- phase 1a (wave 0): start vertex, DFS growth, move type ----
+        // getNewConnectedSet (MultiviewSegmentation.cpp:207-257) is a recursive DFS with one draw per
+        // same-segment neighbour that is not yet in the set.  The wave scans 64 out-edges of the vertex on
+        // top of the stack at once: candidates get the draws nd, nd+1, ... in edge order; the first
+        // success is descended into (draws of later lanes are not consumed: the scan resumes after that
+        // edge when the recursion returns, exactly as the sequential loop does).
+        if (wave == 0) {
             uint32_t nd = 0;
-            const uint32_t start = mv_draw(rg, nd++, sh->rbuf) % (uint32_t)V;
+            const uint32_t start = mv_draw_at(rg, nd++) % (uint32_t)V;
             uint32_t nE = 1; int sp = 1;
-            L.inE[start] = 1; L.elist[0] = (uint16_t)start; L.sv[0] = (uint16_t)start; L.se[0] = g.rowp[start];
+            if (lane == 0) { L.inE[start] = 1; L.elist[0] = (uint16_t)start; L.sv[0] = (uint16_t)start; L.se[0] = g.rowp[start]; }
             const uint16_t cs = L.cur[start];
             while (sp) {
                 const uint32_t v = L.sv[sp - 1];
-                const uint32_t e = L.se[sp - 1];
-                if (e >= g.rowp[v + 1]) { sp--; continue; }
-                L.se[sp - 1] = e + 1;
-                const uint32_t j = g.col[e];
-                if (L.cur[j] != cs) continue;
-                if (L.inE[j]) continue;
-                const double u = mv_unit(mv_draw(rg, nd++, sh->rbuf));
-                if (u <= g.q[e]) {
-                    L.inE[j] = 1; L.elist[nE++] = (uint16_t)j;
-                    L.sv[sp] = (uint16_t)j; L.se[sp] = g.rowp[j]; sp++;
+                uint32_t e0 = L.se[sp - 1];
+                const uint32_t e1 = g.rowp[v + 1];
+                bool descended = false;
+                while (e0 < e1) {
+                    const uint32_t e = e0 + (uint32_t)lane;
+                    uint32_t j = 0;
+                    bool cand = false;
+                    if (e < e1) { j = g.col[e]; cand = L.cur[j] == cs && L.inE[j] == 0; }
+                    const uint64_t m = __ballot(cand);
+                    if (m == 0) { e0 += kWave; continue; }
+                    bool ok = false;
+                    if (cand) ok = mv_unit(mv_draw_at(rg, nd + (uint32_t)mbcnt(m))) <= g.q[e];
+                    const uint64_t sm = __ballot(ok);
+                    if (sm == 0) { nd += (uint32_t)__popcll((unsigned long long)m); e0 += kWave; continue; }
+                    const int first = __ffsll((unsigned long long)sm) - 1;
+                    nd += (uint32_t)__popcll((unsigned long long)(m & ((1ull << first) - 1ull))) + 1u;
+                    const uint32_t js = (uint32_t)__builtin_amdgcn_readlane((int)j, first);
+                    if (lane == 0) {
+                        L.inE[js] = 1; L.elist[nE] = (uint16_t)js;
+                        L.se[sp - 1] = e0 + (uint32_t)first + 1u;
+                        L.sv[sp] = (uint16_t)js; L.se[sp] = g.rowp[js];
+                    }
+                    nE++; sp++;
+                    descended = true;
+                    break;
                 }
+                if (!descended) sp--;
             }
-            const double moveType = mv_unit(mv_draw(rg, nd++, sh->rbuf));
-            sh->start = start; sh->orig = L.own[start]; sh->nE = nE; sh->nd = nd;
-            int kind = 0;
-            if (moveType < a.split_prob) {
-                kind = n_split >= (unsigned long long)(a.seg_cap - V) ? 3 : 1;   // max_new_segments used up
-                sh->target = (uint32_t)nseg;
+            const double moveType = mv_unit(mv_draw_at(rg, nd++));
+            if (lane == 0) {
+                sh->start = start; sh->orig = L.own[start]; sh->nE = nE; sh->nd = nd;
+                int kind = 0;
+                if (moveType < a.split_prob) {
+                    kind = n_split >= (unsigned long long)(a.seg_cap - V) ? 3 : 1;   // max_new_segments used up
+                    sh->target = (uint32_t)nseg;
+                }
+                sh->kind = kind; sh->a = 0.0;
             }
-            sh->kind = kind; sh->a = 0.0;
         }
         __syncthreads();
         const uint32_t nE = sh->nE, orig = sh->orig;
@@ -402,10 +435,10 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         } else {
             // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids
             const uint16_t cs = L.cur[sh->start];
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) {
+            for (uint32_t i = (uint32_t)wave; i < nE; i += kMvWaves) {
                 const uint32_t v = L.elist[i];
                 const uint32_t e1 = g.rowp[v + 1];
-                for (uint32_t e = g.rowp[v]; e < e1; ++e) {
+                for (uint32_t e = g.rowp[v] + (uint32_t)lane; e < e1; e += kWave) {
                     const uint16_t sj = L.cur[g.col[e]];
                     if (sj != cs) L.nb[sj] = 1;
                 }
