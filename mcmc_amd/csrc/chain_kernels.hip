@@ -132,6 +132,37 @@ MC_D uint32_t nth_flag(const uint32_t* words, int NWB, uint32_t idx, int lane)
     return result;
 }
 
+// Lanes of one wave that exchange data through LDS: hardware runs a wave's LDS operations in order, the
+// fence only stops the compiler from reordering or forwarding across it (wavefront scope, no cache action).
+MC_D void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// ---- wave64 inclusive scans in registers (DPP: row_shr 1,2,4,8 then row_bcast 15 / 31) -------
+template <int CTRL, int ROW_MASK>
+MC_D uint32_t dpp_u32(uint32_t identity, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+MC_D uint32_t wave_scan_add_u32(uint32_t v)
+{
+    v += dpp_u32<0x111, 0xf>(0u, v);
+    v += dpp_u32<0x112, 0xf>(0u, v);
+    v += dpp_u32<0x114, 0xf>(0u, v);
+    v += dpp_u32<0x118, 0xf>(0u, v);
+    v += dpp_u32<0x142, 0xa>(0u, v);
+    v += dpp_u32<0x143, 0xc>(0u, v);
+    return v;
+}
+MC_D uint32_t wave_scan_max_u32(uint32_t v)
+{
+    v = max(v, dpp_u32<0x111, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x112, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x114, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x118, 0xf>(0u, v));
+    v = max(v, dpp_u32<0x142, 0xa>(0u, v));
+    v = max(v, dpp_u32<0x143, 0xc>(0u, v));
+    return v;
+}
+
 struct SegFit {
     double probL;
     int n, minid, inf_flag;
@@ -142,7 +173,7 @@ struct SegFit {
 // ---------------------------------------------------------------------------
 struct LdsLayout {
     size_t fit, q, col, rowp, vlist, sv, wave0, wave_bytes, total;
-    size_t w_label, w_queue, w_segN, w_segP, w_inC, w_nflag, w_rbits, w_rpre;
+    size_t w_label, w_queue, w_segN, w_segP, w_inC, w_nflag, w_rbits, w_rpre, w_claim, w_bslot;
 };
 
 __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds)
@@ -167,6 +198,8 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     L.w_nflag = w; w += A((size_t)S);
     L.w_rbits = w; w += A(NW * 4);
     L.w_rpre = w; w += A(NW * 4);
+    L.w_claim = w; w += A((size_t)S * 4);
+    L.w_bslot = w; w += 256;
     L.wave_bytes = w;
     L.total = o + w * (size_t)wpb;
     return L;
@@ -256,12 +289,15 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     const int NWB = (int)(((size_t)S + 15) & ~(size_t)15) / 4;     // words of the flag arrays (zero padded)
     uint32_t* rbits = reinterpret_cast<uint32_t*>(wbase + L.w_rbits);
     uint32_t* rpre = reinterpret_cast<uint32_t*>(wbase + L.w_rpre);
+    uint32_t* claim = reinterpret_cast<uint32_t*>(wbase + L.w_claim);   // lowest lane that joined a node in the current batch
+    uint32_t* bslot = reinterpret_cast<uint32_t*>(wbase + L.w_bslot);   // batch slot -> node of the batch
 
     uint16_t* g_label = a.label + (size_t)chain * a.s_max;
     double* g_segP = a.segP + (size_t)chain * a.s_max;
     uint16_t* g_segN = a.segN + (size_t)chain * a.s_max;
     for (int i = lane; i < S; i += kWave) { label[i] = g_label[i]; segP[i] = g_segP[i]; segN[i] = g_segN[i]; }
     for (int w = lane; w < NWB; w += kWave) { reinterpret_cast<uint32_t*>(inC)[w] = 0u; nflagw[w] = 0u; }
+    for (int i = lane; i < S; i += kWave) claim[i] = 0xFFFFFFFFu;
 
     double energy = a.energy[chain], best_energy = a.best_energy[chain];
     uint64_t state_hash = a.state_hash[chain], trace_hash = a.trace_hash[chain];
@@ -352,48 +388,87 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             const uint32_t orig = label[start];
             MC_PHASE(0);
 
-            // ---- createComponent BFS (Segmentation.cpp:74-120) ----
-            // Queue entries carry the node's CSR row so a pop is one LDS read, prefetched an
-            // iteration early when the entry already exists.
-            uint32_t cur_rs = uni(rowp[start]);
-            uint32_t cur_deg = uni(rowp[start + 1]) - cur_rs;
-            if (lane == 0) { queue[0] = make_uint2(start | (cur_deg << 16), cur_rs); inC[start] = 1; }
-            uint32_t qn = 1, head = 0;
-            while (true) {
-                const bool have_next = head + 1 < qn;
-                uint2 nxt = make_uint2(0u, 0u);
-                if (have_next) nxt = queue[head + 1];
-                for (uint32_t base = 0; base < cur_deg; base += kWave) {
-                    const bool act = base + (uint32_t)lane < cur_deg;
-                    const uint32_t e = cur_rs + base + (uint32_t)lane;
-                    const uint32_t j = act ? colAt(e) : 0u;
-                    const double qe = act ? qv[e] : -1.0;
-                    const bool live = act && !(qe < 0.0);
-                    const bool inc = inC[j] != 0;
-                    const uint32_t lj = label[j];
-                    const bool elig = live && !inc && lj == orig;
-                    const bool oth = live && !inc && lj != orig;
-                    if (oth) nflag[lj] = 1;
-                    const uint64_t em = __ballot(elig);
-                    if (em) {
-                        const double r = rng_unit_varying(g, nd, (uint32_t)mbcnt(em), elig, lane);
-                        nd += (uint32_t)__popcll((unsigned long long)em);
-                        const bool join = elig && (r < qe);  // strict (Segmentation.cpp:110)
-                        const uint64_t jm = __ballot(join);
-                        if (join) {
+            // ---- createComponent BFS (Segmentation.cpp:74-120), batched ----
+            // The reference pops one node at a time and tries its neighbours in order, one draw per
+            // same-segment neighbour that is not yet in the component.  Here the 64 lanes take the next 64
+            // CSR entries of the nodes at the head of the FIFO (several nodes at once; the FIFO order of
+            // entries is the sequential order), evaluate them as if nothing in the batch had joined, give
+            // the eligible ones the draws nd, nd+1, ... in lane order, and then look for the first lane whose
+            // neighbour was joined by an EARLIER lane of the same batch (it would not have been eligible).
+            // Everything before that lane is exactly the sequential result and is committed; the rest is
+            // redone in the next batch (a partly consumed node resumes at `skip`).
+            if (lane == 0) {
+                const uint32_t rs0 = rowp[start];
+                queue[0] = make_uint2(start | ((rowp[start + 1] - rs0) << 16), rs0);
+                inC[start] = 1;
+            }
+            uint32_t qn = 1, head = 0, skip = 0;
+            while (head < qn) {
+                const uint32_t K = min(qn - head, (uint32_t)kWave);
+                uint2 ent = make_uint2(0u, 0u);
+                if ((uint32_t)lane < K) ent = queue[head + (uint32_t)lane];
+                uint32_t deg = ent.x >> 16, rs = ent.y;
+                if (lane == 0) { deg -= skip; rs += skip; }
+                const uint32_t incl = wave_scan_add_u32(deg);
+                const uint32_t excl = incl - deg;
+                // nodes that start inside the 64 slots; the last one may be cut
+                const bool inb = (uint32_t)lane < K && excl < (uint32_t)kWave;
+                const uint32_t M = min((uint32_t)__builtin_amdgcn_readlane((int)incl, uni((int)K - 1)), (uint32_t)kWave);
+                // slot l belongs to the batch node with the largest excl <= l: mark the first slot of every node
+                // (nodes have at least one entry, so excl grows with the node index), max-scan, then pull that
+                // node's row start and first slot
+                // (lanes talk through LDS here: without the fences the compiler forwards a lane's own store
+                // to its load, as the memory model lets it for unsynchronised accesses)
+                bslot[lane] = 0u;
+                wave_fence();
+                if (inb && deg > 0u) bslot[excl] = (uint32_t)lane + 1u;
+                wave_fence();
+                const uint32_t tn = wave_scan_max_u32(bslot[lane]);
+                const bool act = (uint32_t)lane < M;
+                const int src = (int)((tn ? tn - 1u : 0u) * 4u);
+                const uint32_t rs_n = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rs);
+                const uint32_t ex_n = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)excl);
+                const uint32_t e = act ? (rs_n + ((uint32_t)lane - ex_n)) : 0u;
+                const uint32_t j = act ? colAt(e) : 0u;
+                const double qe = act ? qv[e] : -1.0;
+                const bool live = act && !(qe < 0.0);
+                const bool inc = inC[j] != 0;
+                const uint32_t lj = label[j];
+                const uint32_t rj = rowp[j], dj = rowp[j + 1] - rj;
+                const bool elig = live && !inc && lj == orig;
+                const bool oth = live && !inc && lj != orig;
+                if (oth) nflag[lj] = 1;
+                const uint64_t em = __ballot(elig);
+                uint32_t cmt = M;                       // committed slots
+                if (em) {
+                    const double r = rng_unit_varying(g, nd, (uint32_t)mbcnt(em), elig, lane);
+                    const bool join = elig && (r < qe);  // strict (Segmentation.cpp:110)
+                    const uint64_t jm0 = __ballot(join);
+                    if (jm0) {
+                        if (join) atomicMin(&claim[j], (uint32_t)lane);
+                        wave_fence();
+                        const bool late = elig && claim[j] < (uint32_t)lane;   // an earlier lane of this batch took j
+                        wave_fence();
+                        const uint64_t lm = __ballot(late);
+                        if (join) claim[j] = 0xFFFFFFFFu;
+                        if (lm) cmt = (uint32_t)(__ffsll((unsigned long long)lm) - 1);
+                        const bool jc = join && (uint32_t)lane < cmt;
+                        const uint64_t jm = __ballot(jc);
+                        if (jc) {
                             inC[j] = 1;
-                            const uint32_t rj = rowp[j], dj = rowp[j + 1] - rj;
                             queue[qn + (uint32_t)mbcnt(jm)] = make_uint2(j | (dj << 16), rj);
                         }
+                        wave_fence();
                         qn += (uint32_t)__popcll((unsigned long long)jm);
                     }
+                    const uint64_t below = cmt >= 64u ? ~0ull : ((1ull << cmt) - 1ull);
+                    nd += (uint32_t)__popcll((unsigned long long)(em & below));
                 }
-                head++;
-                if (head >= qn) break;
-                if (!have_next) nxt = queue[head];
-                const uint32_t ex = uni(nxt.x);
-                cur_rs = uni(nxt.y);
-                cur_deg = ex >> 16;
+                // advance: nodes whose last slot is committed leave the FIFO; the next one resumes at `skip`
+                const uint32_t nfull = (uint32_t)__popcll((unsigned long long)__ballot(inb && incl <= cmt));
+                const uint32_t done = nfull ? (uint32_t)__builtin_amdgcn_readlane((int)incl, uni((int)nfull - 1)) : 0u;
+                skip = (nfull ? 0u : skip) + (cmt - done);
+                head += nfull;
             }
             const uint32_t csize = qn;
             const bool same = csize == (uint32_t)segN[orig];  // Segmentation.cpp:19
