@@ -389,14 +389,13 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             MC_PHASE(0);
 
             // ---- createComponent BFS (Segmentation.cpp:74-120), batched ----
-            // The reference pops one node at a time and tries its neighbours in order, one draw per
-            // same-segment neighbour that is not yet in the component.  Here the 64 lanes take the next 64
-            // CSR entries of the nodes at the head of the FIFO (several nodes at once; the FIFO order of
-            // entries is the sequential order), evaluate them as if nothing in the batch had joined, give
-            // the eligible ones the draws nd, nd+1, ... in lane order, and then look for the first lane whose
-            // neighbour was joined by an EARLIER lane of the same batch (it would not have been eligible).
-            // Everything before that lane is exactly the sequential result and is committed; the rest is
-            // redone in the next batch (a partly consumed node resumes at `skip`).
+            // The reference pops one node at a time and tries its neighbours in order.  Every trial has its
+            // own counter-addressed uniform (see Rng), so the 64 lanes take the next 64 CSR entries of the
+            // nodes at the head of the FIFO (several nodes at once; the FIFO order of entries is the
+            // sequential order) and try them together.  A node reached through two open edges of one batch
+            // is taken by the lower lane, which is the entry the sequential loop would have reached first,
+            // so the component and the FIFO order are exactly the sequential ones.  A node whose entries
+            // cross the 64th slot resumes at `skip` in the next batch.
             if (lane == 0) {
                 const uint32_t rs0 = rowp[start];
                 queue[0] = make_uint2(start | ((rowp[start + 1] - rs0) << 16), rs0);
@@ -439,31 +438,29 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 const bool oth = live && !inc && lj != orig;
                 if (oth) nflag[lj] = 1;
                 const uint64_t em = __ballot(elig);
-                uint32_t cmt = M;                       // committed slots
                 if (em) {
-                    const double r = rng_unit_varying(g, nd, (uint32_t)mbcnt(em), elig, lane);
+                    // the trial of CSR entry e owns word e&3 of Philox block 0x80000000 | e>>2 of this step
+                    const u32x4 pw = philox4x32_10(u32x4{ g.step_lo, g.step_hi, 0x80000000u | (e >> 2), kPhiloxTag }, g.k0, g.k1);
+                    const uint32_t ws = e & 3u;
+                    const double r = to_unit(ws == 0 ? pw.x : (ws == 1 ? pw.y : (ws == 2 ? pw.z : pw.w)));
                     const bool join = elig && (r < qe);  // strict (Segmentation.cpp:110)
-                    const uint64_t jm0 = __ballot(join);
-                    if (jm0) {
+                    if (__ballot(join)) {
+                        // several lanes may hold an open edge to the same node: the first in FIFO order takes it
                         if (join) atomicMin(&claim[j], (uint32_t)lane);
                         wave_fence();
-                        const bool late = elig && claim[j] < (uint32_t)lane;   // an earlier lane of this batch took j
+                        const bool win = join && claim[j] == (uint32_t)lane;
                         wave_fence();
-                        const uint64_t lm = __ballot(late);
                         if (join) claim[j] = 0xFFFFFFFFu;
-                        if (lm) cmt = (uint32_t)(__ffsll((unsigned long long)lm) - 1);
-                        const bool jc = join && (uint32_t)lane < cmt;
-                        const uint64_t jm = __ballot(jc);
-                        if (jc) {
+                        const uint64_t jm = __ballot(win);
+                        if (win) {
                             inC[j] = 1;
                             queue[qn + (uint32_t)mbcnt(jm)] = make_uint2(j | (dj << 16), rj);
                         }
                         wave_fence();
                         qn += (uint32_t)__popcll((unsigned long long)jm);
                     }
-                    const uint64_t below = cmt >= 64u ? ~0ull : ((1ull << cmt) - 1ull);
-                    nd += (uint32_t)__popcll((unsigned long long)(em & below));
                 }
+                const uint32_t cmt = M;
                 // advance: nodes whose last slot is committed leave the FIFO; the next one resumes at `skip`
                 const uint32_t nfull = (uint32_t)__popcll((unsigned long long)__ballot(inb && incl <= cmt));
                 const uint32_t done = nfull ? (uint32_t)__builtin_amdgcn_readlane((int)incl, uni((int)nfull - 1)) : 0u;

@@ -74,9 +74,19 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 /*
- * Draw d of a step (d = 0, 1, 2, ... in the reference's rand() call order)
- * is word (d>>6)&3 of Philox block (d>>8)*64 + (d&63): a batch of 256 draws
- * is one Philox block per lane of a 64-wide wavefront.
+ * Two families of draws per step, both counter-addressed:
+ *  - the step's scalar draws, in the reference's rand() call order: start
+ *    index, the discarded uniform, selectSegment's two, the MH uniform.  Draw d
+ *    is word (d>>6)&3 of Philox block (d>>8)*64 + (d&63) (one block per lane of
+ *    a 64-wide wavefront).
+ *  - the Swendsen-Wang edge trials of createComponent: the trial of CSR entry e
+ *    (neighbour col[e] tried from the popped node that owns row entry e) uses
+ *    word e&3 of block 0x80000000 | (e>>2).  The reference hands its trials
+ *    whatever rand() returns next; giving every trial its own counter keeps
+ *    them independent uniforms (each directed entry is tried at most once per
+ *    step) and removes the only sequential dependency of the growth, so the GPU
+ *    can try 64 entries of several FIFO nodes at once.  The component, the FIFO
+ *    order and every later decision are unchanged functions of those uniforms.
  */
 typedef struct {
     uint32_t key[2];
@@ -105,6 +115,14 @@ static uint32_t rng_u32(orc_rng *g)
         g->have[lane] = 1;
     }
     return g->buf[lane][w];
+}
+
+/* uniform of the edge trial of CSR entry e */
+static double rng_entry_unif(const orc_rng *g, uint32_t e)
+{
+    uint32_t ctr[4] = { g->step_lo, g->step_hi, 0x80000000u | (e >> 2), PHILOX_TAG }, out[4];
+    orc_philox4x32_10(ctr, g->key, out);
+    return (double)out[e & 3u] / 4294967295.0;
 }
 
 /* rand()/RAND_MAX is inclusive of 1.0 (MCMC.h:223, Segmentation.cpp:23,109). */
@@ -637,7 +655,7 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
             uint32_t j = c->col[e];
             if (c->inC[j]) continue;              /* :94 already in component */
             if (lab[j] != orig) { c->nbr[lab[j]] = 1; continue; } /* :100-105 */
-            double r = rng_unif(&g);              /* :109 */
+            double r = rng_entry_unif(&g, e);     /* :109 */
             if (r < qe) { c->inC[j] = 1; c->queue[qn++] = j; } /* :110-117, strict */
         }
     }
