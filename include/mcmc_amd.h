@@ -36,7 +36,7 @@ extern "C" {
 
 #define MCMC_NOLABEL 0xFFFFu     /* pixel / superpixel that belongs to no superpixel / segment */
 #define MCMC_MOMENT_STRIDE 10    /* N Su Sv Suu Suv Svv Sb Sub Svb Sbb (int64) */
-#define MCMC_FIT_STRIDE 12       /* Suu Suv Svv Su Sv N | Sub Svb Sb | theta_a theta_b theta_c (f64, centred) */
+#define MCMC_FIT_STRIDE 16       /* Suu Suv Svv Su Sv N | Sub Svb Sb | theta_a theta_b theta_c | Sbb ssr 0 0 (f64, centred) */
 
 typedef struct mcmc_ctx mcmc_ctx;
 
@@ -90,7 +90,7 @@ int mcmc_frames_moments(mcmc_ctx *ctx, int first, int count);
 int mcmc_frames_edge_probs(mcmc_ctx *ctx, int first, int count);
 
 int mcmc_frame_get_moments(mcmc_ctx *ctx, int frame, int64_t *out /* S*10 */);
-int mcmc_frame_get_local_fit(mcmc_ctx *ctx, int frame, double *fit /* S*12 */, uint8_t *valid /* S */,
+int mcmc_frame_get_local_fit(mcmc_ctx *ctx, int frame, double *fit /* S*MCMC_FIT_STRIDE */, uint8_t *valid /* S */,
                              double *local_err /* S, Plane::error_, may be NULL */);
 int mcmc_frame_get_edge_probs(mcmc_ctx *ctx, int frame, double *q /* e2; -1 = edge to a dropped superpixel */);
 

@@ -2,7 +2,7 @@
 //
 // One independent Markov chain per 64-lane wavefront; a workgroup of WPB
 // wavefronts shares one frame.  When the frame's tables fit, they are staged
-// in LDS once per launch (fit records 96 B/superpixel, CSR columns as u16,
+// in LDS once per launch (11 sums per superpixel, 88 B, CSR columns as u16,
 // edge probabilities f64) next to each chain's private state (labels, BFS
 // queue, per-segment log-probability cache, bitsets), so a whole run of
 // burn_in+iters steps touches HBM only for statistics.  The step itself is
@@ -33,10 +33,14 @@ constexpr int kLdsLimit = 160 * 1024;
 MC_D size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 static inline size_t h_al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// ---- RNG: a batch of 256 draws is one Philox block per lane ----------------
+// ---- RNG: the uniform at position p of a step is word (p>>6)&3 of Philox block (p>>8)*64 + (p&63),
+// so the 64 lanes generate positions [256 b, 256 b + 256) with one Philox call each.
+// p = 0 start index, 1 discarded, 2 selectSegment uniform, 3 selectSegment index, 4 MH uniform,
+// p = 8 + n: trial of the n-th CSR entry examined by the component growth.
+constexpr uint32_t kTrialPos0 = 8u;
 struct Rng {
-    uint32_t w0, w1, w2, w3;      // raw words (integer draws)
-    double r0, r1, r2, r3;        // the same draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
+    uint32_t w0;                  // raw word 0 (integer draws of positions 0..63)
+    double r0, r1, r2, r3;        // the draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
     uint32_t k0, k1, step_lo, step_hi;
     int batch;
 };
@@ -47,54 +51,29 @@ MC_D void rng_gen(Rng& g, int batch, int lane)
 {
     u32x4 c = { g.step_lo, g.step_hi, (uint32_t)(batch * 64 + lane), kPhiloxTag };
     u32x4 r = philox4x32_10(c, g.k0, g.k1);
-    g.w0 = r.x; g.w1 = r.y; g.w2 = r.z; g.w3 = r.w;
-    // the divisions are done once per batch, off the BFS critical path
+    g.w0 = r.x;
+    // the divisions are done once per 256 positions, off the BFS critical path
     g.r0 = to_unit(r.x); g.r1 = to_unit(r.y); g.r2 = to_unit(r.z); g.r3 = to_unit(r.w);
     g.batch = batch;
 }
 
-// integer draw, d wave-uniform
-MC_D uint32_t rng_uniform_idx(Rng& g, uint32_t d, int lane)
+// Uniforms of positions p0 + lane (p0 wave-uniform) for the lanes that `need` one.  Position p lives in
+// lane p & 63 of its batch, and the 64 consecutive positions of a pass hit every source lane once, so a
+// source lane knows its one consumer, picks the word that consumer wants, and the consumer pulls it.
+MC_D double rng_trial(Rng& g, uint32_t p0, bool need, int lane)
 {
-    d = uni(d);
-    const int b = (int)(d >> 8);
-    if (b != g.batch) rng_gen(g, b, lane);
-    const uint32_t ws = (d >> 6) & 3u;
-    const uint32_t v = ws == 0 ? g.w0 : (ws == 1 ? g.w1 : (ws == 2 ? g.w2 : g.w3));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(d & 63u));
-}
-
-// unit draw, d wave-uniform
-MC_D double rng_unit_uniform(Rng& g, uint32_t d, int lane)
-{
-    d = uni(d);
-    const int b = (int)(d >> 8);
-    if (b != g.batch) rng_gen(g, b, lane);
-    const uint32_t ws = (d >> 6) & 3u;
-    const double v = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
-    const uint64_t u = d2u(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)(d & 63u));
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)(d & 63u));
-    return u2d(((uint64_t)hi << 32) | lo);
-}
-
-// unit draws d0 + rank for the lanes that `need` one (rank = 0, 1, 2, ... in lane order)
-MC_D double rng_unit_varying(Rng& g, uint32_t d0, uint32_t rank, bool need, int lane)
-{
-    const uint32_t d = d0 + rank;
-    double res = 0.0;
-    uint64_t m = __ballot(need);
-    while (m) {  // one pass unless the draws cross a 64-draw block
-        const int first = __ffsll((unsigned long long)m) - 1;
-        const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)d, first) >> 6;
-        const int b = (int)(blk >> 2);
-        if (b != g.batch) rng_gen(g, b, lane);
-        const uint32_t ws = blk & 3u;
-        const double sel = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
-        const bool mine = need && (d >> 6) == blk;
-        const double v = __shfl(sel, (int)(d & 63u), kWave);
-        if (mine) res = v;
-        m &= ~__ballot(mine);
+    const uint32_t p = p0 + (uint32_t)lane;
+    const uint32_t pc = p0 + (((uint32_t)lane - p0) & 63u);   // position this lane serves
+    const uint32_t ws = (pc >> 6) & 3u;
+    const int b0 = (int)(p0 >> 8);
+    if (b0 != g.batch) rng_gen(g, b0, lane);
+    double sel = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
+    double res = __shfl(sel, (int)(p & 63u), kWave);
+    if (__ballot(need && (int)(p >> 8) != b0)) {              // the pass crosses into the next 256 positions
+        rng_gen(g, b0 + 1, lane);
+        sel = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
+        const double v = __shfl(sel, (int)(p & 63u), kWave);
+        if ((int)(p >> 8) != b0) res = v;
     }
     return res;
 }
@@ -163,6 +142,9 @@ MC_D uint32_t wave_scan_max_u32(uint32_t v)
     return v;
 }
 
+// per-superpixel record of the chain kernel: the 10 exact sums and ssr (fit record entries 0..8, 12, 13)
+constexpr int kRecStride = 11;
+
 struct SegFit {
     double probL;
     int n, minid, inf_flag;
@@ -181,7 +163,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsLayout L;
     size_t o = 0;
-    L.fit = o; if (tab_lds) o += A((size_t)S * kFitStride * 8);
+    L.fit = o; if (tab_lds) o += A((size_t)S * kRecStride * 8);
     L.q = o; if (tab_lds) o += A((size_t)E2 * 8);
     L.col = o; if (tab_lds) o += A((size_t)E2 * 2);
     L.rowp = o; if (tab_lds) o += A((size_t)(S + 1) * 4);
@@ -247,7 +229,10 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     // ---- stage the frame tables (block-cooperative) ----
     if (TAB_LDS) {
-        for (int i = tid; i < S * kFitStride; i += WPB * 64) l_fit[i] = g_fit[i];
+        for (int i = tid; i < S * kRecStride; i += WPB * 64) {
+            const int sp = i / kRecStride, k = i - sp * kRecStride;
+            l_fit[i] = g_fit[(size_t)sp * kFitStride + (k < 9 ? k : k + 3)];
+        }
         for (int i = tid; i < E2; i += WPB * 64) { l_q[i] = g_q[i]; l_col[i] = (uint16_t)g_col[i]; }
         for (int i = tid; i <= S; i += WPB * 64) l_rowp[i] = g_rowp[i];
     }
@@ -270,9 +255,14 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     if (chain >= a.n_chains || Sv == 0) return;
 
     // ---- table accessors: LDS or HBM/L2 ----
-    const double* fit; const double* qv; const uint32_t* rowp;
-    if constexpr (TAB_LDS) { fit = l_fit; qv = l_q; rowp = l_rowp; }
-    else { fit = g_fit; qv = g_q; rowp = g_rowp; }
+    const double* qv; const uint32_t* rowp;
+    if constexpr (TAB_LDS) { qv = l_q; rowp = l_rowp; }
+    else { qv = g_q; rowp = g_rowp; }
+    // sums of superpixel i: 0..8 the moments, 9 Sbb, 10 ssr
+    auto recAt = [&](uint32_t i, int k) -> double {
+        if constexpr (TAB_LDS) return l_fit[(size_t)i * kRecStride + k];
+        else return g_fit[(size_t)i * kFitStride + (k < 9 ? k : k + 3)];
+    };
     auto colAt = [&](uint32_t e) -> uint32_t {
         if constexpr (TAB_LDS) return (uint32_t)l_col[e]; else return g_col[e];
     };
@@ -294,6 +284,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     uint16_t* g_label = a.label + (size_t)chain * a.s_max;
     double* g_segP = a.segP + (size_t)chain * a.s_max;
+    double* g_segC = a.segC + (size_t)chain * a.s_max * kSegCacheStride;
     uint16_t* g_segN = a.segN + (size_t)chain * a.s_max;
     for (int i = lane; i < S; i += kWave) { label[i] = g_label[i]; segP[i] = g_segP[i]; segN[i] = g_segN[i]; }
     for (int w = lane; w < NWB; w += kWave) { reinterpret_cast<uint32_t*>(inC)[w] = 0u; nflagw[w] = 0u; }
@@ -310,7 +301,6 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     const double var = a.var, nsp = a.new_seg_prob;
     const double log_var = det_log(var);
-    const double inv2var_den = 2.0 * var;
 
     Rng g;
     g.k0 = a.seed; g.k1 = a.chain_offset + (uint32_t)chain;
@@ -379,12 +369,14 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
         const unsigned long long t = a.step0 + ts;
         uint8_t tb = 0xFF;
         if (status == 0) {
-            g.step_lo = (uint32_t)t; g.step_hi = (uint32_t)(t >> 32); g.batch = -1;
-            uint32_t nd = 0;
-
-            // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161)
-            const uint32_t start = vlist[rng_uniform_idx(g, nd, lane) % (uint32_t)Sv];
-            nd += 2;
+            g.step_lo = (uint32_t)t; g.step_hi = (uint32_t)(t >> 32);
+            rng_gen(g, 0, lane);
+            // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161); the step's other
+            // scalar draws are taken out of the batch now, before the growth moves on to later positions
+            const uint32_t start = vlist[(uint32_t)__builtin_amdgcn_readlane((int)g.w0, 0) % (uint32_t)Sv];
+            const double u1 = readlane_f64(g.r0, 2);
+            const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)g.w0, 3);
+            const double r_mh = readlane_f64(g.r0, 4);
             const uint32_t orig = label[start];
             MC_PHASE(0);
 
@@ -401,7 +393,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 queue[0] = make_uint2(start | ((rowp[start + 1] - rs0) << 16), rs0);
                 inC[start] = 1;
             }
-            uint32_t qn = 1, head = 0, skip = 0;
+            uint32_t qn = 1, head = 0, skip = 0, npos = kTrialPos0;
             while (head < qn) {
                 const uint32_t K = min(qn - head, (uint32_t)kWave);
                 uint2 ent = make_uint2(0u, 0u);
@@ -439,10 +431,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 if (oth) nflag[lj] = 1;
                 const uint64_t em = __ballot(elig);
                 if (em) {
-                    // the trial of CSR entry e owns word e&3 of Philox block 0x80000000 | e>>2 of this step
-                    const u32x4 pw = philox4x32_10(u32x4{ g.step_lo, g.step_hi, 0x80000000u | (e >> 2), kPhiloxTag }, g.k0, g.k1);
-                    const uint32_t ws = e & 3u;
-                    const double r = to_unit(ws == 0 ? pw.x : (ws == 1 ? pw.y : (ws == 2 ? pw.z : pw.w)));
+                    const double r = rng_trial(g, npos, elig, lane);
                     const bool join = elig && (r < qe);  // strict (Segmentation.cpp:110)
                     if (__ballot(join)) {
                         // several lanes may hold an open edge to the same node: the first in FIFO order takes it
@@ -466,13 +455,14 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 const uint32_t done = nfull ? (uint32_t)__builtin_amdgcn_readlane((int)incl, uni((int)nfull - 1)) : 0u;
                 skip = (nfull ? 0u : skip) + (cmt - done);
                 head += nfull;
+                npos += M;
+                if constexpr (PROF) pacc[15] += 1;
             }
             const uint32_t csize = qn;
             const bool same = csize == (uint32_t)segN[orig];  // Segmentation.cpp:19
             MC_PHASE(1);
 
             // ---- selectSegment (Segmentation.cpp:10-57) ----
-            const double u1 = rng_unit_uniform(g, nd, lane); nd += 1;
             int kase; uint32_t next = orig; double ratio;
             if (!same && u1 < nsp) { kase = 1; ratio = nsp; }
             else {
@@ -480,7 +470,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 for (int w = lane; w < NWB; w += kWave) nnl += __popc(nflagw[w]);
                 const uint32_t numSeg = (uint32_t)wave_sum_i32(nnl) + 1u;
                 const double existing = same ? 1.0 : (1.0 - nsp);
-                const uint32_t idx = rng_uniform_idx(g, nd, lane) % numSeg; nd += 1;
+                const uint32_t idx = idx_draw % numSeg;
                 if (idx == numSeg - 1u) { kase = 0; next = orig; }
                 else { kase = 2; next = nth_flag(nflagw, NWB, idx, lane); }
                 ratio = existing / (double)numSeg;
@@ -489,14 +479,34 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             MC_PHASE(2);
             double targetL = 1.0, prop = ratio;  // Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic)
             SegFit f1 = { 0.0, 0, 0, 0 }, f2 = { 0.0, 0, 0, 0 };
+            double M2[kSumStride], M1[kSumStride], R2 = 0.0, R1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < kSumStride; ++k) { M2[k] = 0.0; M1[k] = 0.0; }
             int st = 0;
-            const bool have1 = !(kase == 2 && same);
+            const bool have1 = !same;  // sB1 = sA1 minus the component is not empty
             if (kase != 0) {
-                // separation / merge products over the component's cut edges
-                // (Segmentation.cpp:127-146; Graph.cpp:10-33), wave order over the queue
-                double ps = 1.0, pm = 1.0;
+                // cached sums of the two segments (Segment::combine / diff on sums instead of a refit from the
+                // member list, Graph.cpp:35-67): issued now, needed after the pass over the component
+                double Co[kSumStride + 1], Cn[kSumStride + 1];
+#pragma unroll
+                for (int k = 0; k <= kSumStride; ++k) {
+                    Co[k] = have1 ? __hip_atomic_load(g_segC + (size_t)orig * kSegCacheStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    Cn[k] = kase == 2 ? __hip_atomic_load(g_segC + (size_t)next * kSegCacheStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                }
+                // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
+                // Graph.cpp:10-33) and the component's sums, wave order over the queue
+                double ps = 1.0, pm = 1.0, rp = 0.0;
+                double mc[kSumStride];
+#pragma unroll
+                for (int k = 0; k < kSumStride; ++k) mc[k] = 0.0;
+                int mn = 0x7FFFFFFF;
                 for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) {
                     const uint2 ent = queue[h];
+                    const uint32_t i = ent.x & 0xFFFFu;
+#pragma unroll
+                    for (int k = 0; k < kSumStride; ++k) mc[k] += recAt(i, k);
+                    rp += recAt(i, kSumStride);
+                    mn = min(mn, (int)i);
                     const uint32_t rs = ent.y, re = ent.y + (ent.x >> 16);
                     for (uint32_t e = rs; e < re; ++e) {
                         const double qe = qv[e];
@@ -507,90 +517,56 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                         else if (kase == 2 && lj == next) pm = pm * (1.0 - qe);
                     }
                 }
-                const double sep = wave_prod_f64(ps);
                 MC_PHASE(3);
-
-                // ---- fused fits of sB2 (code 2) and sB1 (code 1): pass 1, exact sums ----
-                double s2[9], s1[9];
+                const double sep = wave_prod_f64(ps);
+                const double mrg = kase == 2 ? wave_prod_f64(pm) : 1.0;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) { s2[k] = 0.0; s1[k] = 0.0; }
-                int n2 = 0, n1 = 0, m2 = 0x7FFFFFFF, m1 = 0x7FFFFFFF;
-                for (int i = lane; i < S; i += kWave) {
-                    const uint32_t li = label[i];
-                    if (li == kNoLabel) continue;
-                    const bool inc = inC[i] != 0;
-                    int m;
-                    if (kase == 1) m = inc ? 2 : (li == orig ? 1 : 0);
-                    else m = (inc || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
-                    if (m == 2) {
-                        const double* f = fit + (size_t)i * kFitStride;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) s2[k] += f[k];
-                        n2++; m2 = min(m2, i);
-                    } else if (m == 1) {
-                        const double* f = fit + (size_t)i * kFitStride;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) s1[k] += f[k];
-                        n1++; m1 = min(m1, i);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 9; ++k) s2[k] = wave_sum_f64(s2[k]);  // integer-valued: exact, order-free
-                n2 = wave_sum_i32(n2); m2 = wave_min_i32(m2);
-                if (have1) {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) s1[k] = wave_sum_f64(s1[k]);
-                    n1 = wave_sum_i32(n1); m1 = wave_min_i32(m1);
-                }
+                for (int k = 0; k < kSumStride; ++k) mc[k] = wave_sum_f64(mc[k]);  // integer-valued: exact, order-free
+                const double Rc = wave_sum_f64(rp);
+                const int minC = wave_min_i32(mn);
                 MC_PHASE(4);
-                Vec3 th2, d2, th1 = { 0, 0, 0 }, d1 = { 1, 1, 1 };
+#pragma unroll
+                for (int k = 0; k < kSumStride; ++k) { M2[k] = kase == 2 ? Cn[k] + mc[k] : mc[k]; M1[k] = Co[k] - mc[k]; }
+                R2 = kase == 2 ? Cn[kSumStride] + Rc : Rc;
+                R1 = Co[kSumStride] - Rc;
+                // the two evaluations run side by side: lanes 0..31 take sB2, lanes 32..63 sB1
                 {
-                    Sym3 A2 = { s2[0], s2[1], s2[2], s2[3], s2[4], s2[5] };
-                    Vec3 r2 = { s2[6], s2[7], s2[8] };
-                    ldl3(A2, r2, th2, d2);
+                    const bool hi = lane >= 32;
+                    double ms[kSumStride];
+#pragma unroll
+                    for (int k = 0; k < kSumStride; ++k) ms[k] = hi ? M1[k] : M2[k];
+                    if (hi && !have1) {   // no sB1: keep the arithmetic finite, the result is not used
+#pragma unroll
+                        for (int k = 0; k < kSumStride; ++k) ms[k] = M2[k];
+                    }
+                    Vec3 th; double err; int inf = 0;
+                    const double p = segment_from_sums(ms, hi ? R1 : R2, var, log_var, th, err, &inf);
+                    f2.probL = readlane_f64(p, 0);
+                    f1.probL = have1 ? readlane_f64(p, 32) : 0.0;
+                    const uint64_t im = __ballot(inf != 0);
+                    f2.inf_flag = (int)(im & 1ull);
+                    f1.inf_flag = have1 ? (int)((im >> 32) & 1ull) : 0;
                 }
-                if (have1) {
-                    Sym3 A1 = { s1[0], s1[1], s1[2], s1[3], s1[4], s1[5] };
-                    Vec3 r1 = { s1[6], s1[7], s1[8] };
-                    ldl3(A1, r1, th1, d1);
-                }
+                f2.n = (int)csize + (kase == 2 ? (int)segN[next] : 0);
+                f2.minid = (kase == 2 && (int)next < minC) ? (int)next : minC;
+                f1.n = have1 ? (int)segN[orig] - (int)csize : 0;
                 MC_PHASE(5);
-                // ---- pass 2: factor errors at the fused mean (MyMath.h:247-252), wave order ----
-                double e2p = 0.0, e1p = 0.0;
-                for (int i = lane; i < S; i += kWave) {
-                    const uint32_t li = label[i];
-                    if (li == kNoLabel) continue;
-                    const bool inc = inC[i] != 0;
-                    int m;
-                    if (kase == 1) m = inc ? 2 : (li == orig ? 1 : 0);
-                    else m = (inc || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
-                    if (m == 2) e2p += member_quad(fit + (size_t)i * kFitStride, th2);
-                    else if (m == 1) e1p += member_quad(fit + (size_t)i * kFitStride, th1);
-                }
-                MC_PHASE(6);
-                const double err2 = wave_sum_f64(e2p) / inv2var_den;
-                f2.probL = segment_logprob(err2, d2, log_var, &f2.inf_flag);
-                f2.n = n2; f2.minid = m2;
-                if (have1) {
-                    const double err1 = wave_sum_f64(e1p) / inv2var_den;
-                    f1.probL = segment_logprob(err1, d1, log_var, &f1.inf_flag);
-                    f1.n = n1; f1.minid = m1;
-                }
                 if (kase == 1) prop = ratio * (1.0 / sep);              // Problem.cpp:188
-                else prop = ratio * (wave_prod_f64(pm) / sep);          // Problem.cpp:206
+                else prop = ratio * (mrg / sep);                        // Problem.cpp:206
                 // jumpProbability (Problem.cpp:475-487)
                 const double sB2_sA1 = f2.probL - segP[orig];
                 const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? segP[next] : 0.0);
                 targetL = sB2_sA1 + sB1_sA2;
                 if (f1.inf_flag || f2.inf_flag) st = -5;
                 if (targetL != targetL || prop != prop) st = -4;        // Problem.cpp:216-217
+                MC_PHASE(6);
             }
 
             MC_PHASE(7);
             // ---- FastMetropolisHastings::iterate (MCMC.h:218-227) ----
             const double aL = targetL + det_log(prop);
             const double acc = det_exp(aL);
-            const double r = rng_unit_uniform(g, nd, lane); nd += 1;  // always drawn
+            const double r = r_mh;  // always drawn
             bool accept = true;
             if (aL < 0.0) { if (r > acc) accept = false; }
             if (st != 0) { accept = false; status = st; }
@@ -601,16 +577,21 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 flush_stats();  // leaving the current state
                 MC_PHASE(9);
                 // jump (Problem.cpp:32-74) with smallest-member naming
-                const uint32_t L2 = (uint32_t)f2.minid, L1 = (uint32_t)(f1.n ? f1.minid : 0);
+                const uint32_t L2 = (uint32_t)f2.minid;
+                uint32_t L1 = orig;
+                if (have1 && inC[orig]) {   // the old name moves with the component: smallest id left behind
+                    int m1 = 0x7FFFFFFF;
+                    for (int i = lane; i < S; i += kWave)
+                        if (label[i] == orig && !inC[i]) m1 = min(m1, i);
+                    L1 = (uint32_t)wave_min_i32(m1);
+                }
                 uint64_t dh = 0;
                 for (int i = lane; i < S; i += kWave) {
                     const uint32_t li = label[i];
                     if (li == kNoLabel) continue;
-                    const bool inc = inC[i] != 0;
-                    int m;
-                    if (kase == 1) m = inc ? 2 : (li == orig ? 1 : 0);
-                    else m = (inc || li == next) ? 2 : ((li == orig && !same) ? 1 : 0);
-                    const uint32_t nl = m == 2 ? L2 : (m == 1 ? L1 : li);
+                    uint32_t nl = li;
+                    if (inC[i] || (kase == 2 && li == next)) nl = L2;
+                    else if (have1 && li == orig) nl = L1;
                     if (nl != li) {
                         dh += mix64(((uint64_t)i << 32) | nl) - mix64(((uint64_t)i << 32) | li);
                         label[i] = (uint16_t)nl;
@@ -619,8 +600,18 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 state_hash += wave_sum_u64(dh);
                 if (lane == 0) {
                     segP[L2] = f2.probL; segN[L2] = (uint16_t)f2.n;
-                    if (f1.n) { segP[L1] = f1.probL; segN[L1] = (uint16_t)f1.n; }
+                    if (have1) { segP[L1] = f1.probL; segN[L1] = (uint16_t)f1.n; }
                 }
+                // the new segments' sums go to the cache; the stores are complete (in L2) before any later
+                // step of this wave reads them back with an L2 (agent scope) load
+                if (lane <= kSumStride) {
+                    double v2 = R2, v1 = R1;
+#pragma unroll
+                    for (int k = 0; k < kSumStride; ++k) if (lane == k) { v2 = M2[k]; v1 = M1[k]; }
+                    g_segC[(size_t)L2 * kSegCacheStride + lane] = v2;
+                    if (have1) g_segC[(size_t)L1 * kSegCacheStride + lane] = v1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 energy += targetL;
                 if (energy > best_energy) {
                     best_energy = energy;
@@ -630,7 +621,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 newlab = L2;
             }
             MC_PHASE(10);
-            if constexpr (PROF) { pacc[12] += csize; pacc[13] += nd; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
+            if constexpr (PROF) { pacc[12] += csize; pacc[13] += npos; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
             if (accept) n_accept++;
             if (kase == 0) n_case0++; else if (kase == 1) n_case1++; else n_case2++;
 
@@ -677,29 +668,28 @@ __global__ __launch_bounds__(64) void chain_init_kernel(ChainArgs a)
     const int S = a.S[frame];
     const double* fit = a.fit + (size_t)frame * a.s_max * kFitStride;
     const uint8_t* valid = a.valid + (size_t)frame * a.s_max;
-    double s[9];
+    double s[kSumStride];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    for (int k = 0; k < kSumStride; ++k) s[k] = 0.0;
+    double rp = 0.0;
     int n = 0, mn = 0x7FFFFFFF;
     for (int i = lane; i < S; i += kWave) {
         if (!valid[i]) continue;
         const double* f = fit + (size_t)i * kFitStride;
 #pragma unroll
         for (int k = 0; k < 9; ++k) s[k] += f[k];
+        s[9] += f[12];
+        rp += f[13];
         n++; mn = min(mn, i);
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = wave_sum_f64(s[k]);
+    for (int k = 0; k < kSumStride; ++k) s[k] = wave_sum_f64(s[k]);
+    const double R = wave_sum_f64(rp);
     n = wave_sum_i32(n); mn = wave_min_i32(mn);
     double p = 0.0; int inf_flag = 0;
     if (n > 0) {
-        Sym3 A = { s[0], s[1], s[2], s[3], s[4], s[5] };
-        Vec3 r = { s[6], s[7], s[8] }, th, d;
-        ldl3(A, r, th, d);
-        double ep = 0.0;
-        for (int i = lane; i < S; i += kWave)
-            if (valid[i]) ep += member_quad(fit + (size_t)i * kFitStride, th);
-        p = segment_logprob(wave_sum_f64(ep) / (2.0 * a.var), d, det_log(a.var), &inf_flag);
+        Vec3 th; double err;
+        p = segment_from_sums(s, R, a.var, det_log(a.var), th, err, &inf_flag);
     }
     const uint16_t root = n > 0 ? (uint16_t)mn : (uint16_t)0;
     uint16_t* lab = a.label + (size_t)chain * a.s_max;
@@ -717,6 +707,12 @@ __global__ __launch_bounds__(64) void chain_init_kernel(ChainArgs a)
         if (ok) h += mix64(((uint64_t)i << 32) | l);
     }
     h = wave_sum_u64(h);
+    if (n > 0 && lane <= kSumStride) {
+        double v = R;
+#pragma unroll
+        for (int k = 0; k < kSumStride; ++k) if (lane == k) v = s[k];
+        a.segC[((size_t)chain * a.s_max + root) * kSegCacheStride + lane] = v;
+    }
     for (int i = lane; i < a.hcap; i += kWave) {
         a.visit_hash[(size_t)chain * a.hcap + i] = 0ull;
         a.visit_count[(size_t)chain * a.hcap + i] = 0ull;

@@ -17,7 +17,8 @@ namespace mc {
 
 constexpr int kWave = 64;
 constexpr int kMomStride = 10;
-constexpr int kFitStride = 12;
+constexpr int kFitStride = 16;   // Suu Suv Svv Su Sv N | Sub Svb Sb | theta a b c | Sbb ssr 0 0
+constexpr int kSumStride = 10;   // Suu Suv Svv Su Sv N Sub Svb Sb Sbb (exact, integer valued)
 constexpr uint16_t kNoLabel = 0xFFFFu;
 constexpr double kLog2Pi = 1.8378770664093453;
 
@@ -115,7 +116,8 @@ MC_HD double det_exp(double x)
 struct Sym3 { double a11, a12, a22, a13, a23, a33; };
 struct Vec3 { double x, y, z; };
 
-MC_HD void ldl3(const Sym3& a, const Vec3& r, Vec3& x, Vec3& d)
+// Returns r' A^-1 r from the factorisation (sum y_k^2 / d_k): the residual of the fit is b'b minus it.
+MC_HD double ldl3(const Sym3& a, const Vec3& r, Vec3& x, Vec3& d)
 {
     double d1 = a.a11;
     double l21 = a.a12 / d1;
@@ -133,17 +135,7 @@ MC_HD void ldl3(const Sym3& a, const Vec3& r, Vec3& x, Vec3& d)
     double x1 = (z1 - l21 * x2) - l31 * x3;
     x.x = x1; x.y = x2; x.z = x3;
     d.x = d1; d.y = d2; d.z = d3;
-}
-
-// Residual of one member against the fused plane: (theta-theta_i)' M_i (theta-theta_i).
-// f points at the member's 12-double fit record.
-template <typename P>
-MC_HD double member_quad(const P f, const Vec3& th)
-{
-    double da = th.x - f[9], db = th.y - f[10], dc = th.z - f[11];
-    return da * ((f[0] * da + f[1] * db) + f[3] * dc)
-         + db * ((f[1] * da + f[2] * db) + f[4] * dc)
-         + dc * ((f[3] * da + f[4] * db) + f[5] * dc);
+    return (y1 * z1 + y2 * z2) + y3 * z3;
 }
 
 // probabilityL_ from the error sum (already divided by 2 var) and the LDL pivots.
@@ -154,6 +146,19 @@ MC_HD double segment_logprob(double err, const Vec3& d, double log_var, int* inf
     if (p != p) p = 0.75;                 // Graph.cpp:134
     if (p - p != 0.0) *inf_flag = 1;      // Graph.cpp:137
     return p;
+}
+
+// probabilityL_ of a segment from its sums: m[10] exact (kSumStride order), R = sum of the members' ssr.
+// 2 var * totalError = (Sbb - m' M^-1 m) - R: the members' factor errors at the fused mean
+// (MyMath.h:247-252) written as residual at theta minus the members' own residuals.
+template <typename P>
+MC_HD double segment_from_sums(const P m, double R, double var, double log_var, Vec3& th, double& err, int* inf_flag)
+{
+    Sym3 A = { m[0], m[1], m[2], m[3], m[4], m[5] };
+    Vec3 r = { m[6], m[7], m[8] }, d;
+    const double quad = ldl3(A, r, th, d);
+    err = ((m[9] - quad) - R) / (2.0 * var);
+    return segment_logprob(err, d, log_var, inf_flag);
 }
 
 MC_HD uint64_t mix64(uint64_t x)
@@ -175,17 +180,44 @@ MC_D int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Fixed-shape xor butterfly, offsets 1,2,4,8,16,32: every lane ends with the
 // same bits, and a CPU loop over 64 partials reproduces them exactly.
+// The exchanges run on the DPP crossbar instead of ds_bpermute: after the xor-1
+// and xor-2 steps (quad_perm) every lane of a quad holds the same value, so the
+// xor-4 partner may be any lane of the other quad of the 8-group (row_half_mirror)
+// and the xor-8 partner any lane of the other 8-group of the row (row_mirror);
+// IEEE + and * are commutative, so the bits are those of the xor butterfly.  The
+// last two steps combine the four row values: (r0 op r1) op (r2 op r3).
+template <int CTRL>
+MC_D double dpp_f64(double v)
+{
+    const uint64_t u = d2u(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    return u2d(((uint64_t)hi << 32) | lo);
+}
+MC_D double readlane_f64(double v, int src)
+{
+    const uint64_t u = d2u(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+    return u2d(((uint64_t)hi << 32) | lo);
+}
 MC_D double wave_sum_f64(double v)
 {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
-    return v;
+    v = v + dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = v + dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = v + dpp_f64<0x141>(v);   // row_half_mirror
+    v = v + dpp_f64<0x140>(v);   // row_mirror
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 MC_D double wave_prod_f64(double v)
 {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) v = v * __shfl_xor(v, off, kWave);
-    return v;
+    v = v * dpp_f64<0xB1>(v);
+    v = v * dpp_f64<0x4E>(v);
+    v = v * dpp_f64<0x141>(v);
+    v = v * dpp_f64<0x140>(v);
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return (r0 * r1) * (r2 * r3);
 }
 MC_D uint64_t wave_sum_u64(uint64_t v)
 {
@@ -195,15 +227,21 @@ MC_D uint64_t wave_sum_u64(uint64_t v)
 }
 MC_D int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 MC_D int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) { int o = __shfl_xor(v, off, kWave); v = o < v ? o : v; }
-    return v;
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 }  // namespace mc

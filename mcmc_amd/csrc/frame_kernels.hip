@@ -787,16 +787,17 @@ __global__ void local_fit_kernel(FitArgs a)
     f[0] = (double)suu; f[1] = (double)suv; f[2] = (double)svv;
     f[3] = (double)su;  f[4] = (double)sv;  f[5] = (double)n;
     f[6] = (double)sub; f[7] = (double)svb; f[8] = (double)sb;
-    double le = 0.0;
+    double le = 0.0, ssr = 0.0;
     Vec3 x = { 0.0, 0.0, 0.0 };
     if (ok) {
         Sym3 A = { f[0], f[1], f[2], f[3], f[4], f[5] };
         Vec3 r = { f[6], f[7], f[8] }, d;
-        ldl3(A, r, x, d);
-        double sse = (double)m[9] - ((x.x * r.x + x.y * r.y) + x.z * r.z);
-        le = sse / (2.0 * a.var);
+        const double quad = ldl3(A, r, x, d);
+        ssr = (double)m[9] - quad;
+        le = ssr / (2.0 * a.var);
     }
     f[9] = x.x; f[10] = x.y; f[11] = x.z;
+    f[12] = (double)m[9]; f[13] = ssr; f[14] = 0.0; f[15] = 0.0;
     a.local_err[(size_t)frame * a.s_max + s] = le;
 }
 
@@ -823,24 +824,21 @@ __global__ void edge_prob_kernel(EdgeArgs a)
     const double* fj = a.fit + ((size_t)frame * a.s_max + j) * kFitStride;
     const double log_var = det_log(a.var);
     int inf_flag = 0;
-    // together {i, j}
-    Sym3 A = { fi[0] + fj[0], fi[1] + fj[1], fi[2] + fj[2], fi[3] + fj[3], fi[4] + fj[4], fi[5] + fj[5] };
-    Vec3 r = { fi[6] + fj[6], fi[7] + fj[7], fi[8] + fj[8] }, x, d;
-    ldl3(A, r, x, d);
-    const double ei = member_quad(fi, x), ej = member_quad(fj, x);
-    // wave-order sum of two members (same lane or butterfly of two non-zeros among zeros):
-    // one IEEE addition either way, and a + b == b + a.
-    const double esum = ei + ej;
-    const double T = segment_logprob(esum / (2.0 * a.var), d, log_var, &inf_flag);
-    // separate {i}, {j}: residual is exactly zero
-    Sym3 Ai = { fi[0], fi[1], fi[2], fi[3], fi[4], fi[5] };
-    Vec3 ri = { fi[6], fi[7], fi[8] }, xi, di;
-    ldl3(Ai, ri, xi, di);
-    Sym3 Aj = { fj[0], fj[1], fj[2], fj[3], fj[4], fj[5] };
-    Vec3 rj = { fj[6], fj[7], fj[8] }, xj, dj;
-    ldl3(Aj, rj, xj, dj);
-    const double pi = segment_logprob(member_quad(fi, xi) / (2.0 * a.var), di, log_var, &inf_flag);
-    const double pj = segment_logprob(member_quad(fj, xj) / (2.0 * a.var), dj, log_var, &inf_flag);  // quad == 0
+    // together {i, j}: sums of two records; the wave-order sum of two ssr values is one IEEE addition
+    // whichever lanes they sit in, and a + b == b + a
+    double mt[kSumStride];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) mt[k] = fi[k] + fj[k];
+    mt[9] = fi[12] + fj[12];
+    Vec3 x; double err;
+    const double T = segment_from_sums(mt, fi[13] + fj[13], a.var, log_var, x, err, &inf_flag);
+    // separate {i}, {j}: the residual is exactly zero (same operations as the local fit)
+    double mi[kSumStride], mj[kSumStride];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { mi[k] = fi[k]; mj[k] = fj[k]; }
+    mi[9] = fi[12]; mj[9] = fj[12];
+    const double pi = segment_from_sums(mi, fi[13], a.var, log_var, x, err, &inf_flag);
+    const double pj = segment_from_sums(mj, fj[13], a.var, log_var, x, err, &inf_flag);
     const double Sp = pi + pj;
     double lB, lS;
     if (T > Sp) { lB = T; lS = Sp; } else { lS = T; lB = Sp; }
@@ -860,34 +858,28 @@ __global__ __launch_bounds__(64) void segment_prob_kernel(SegArgs a)
     const int lane = lane_id();
     const int S = a.S;
     const double* fit = a.fit;
-    double acc[9];
+    double acc[kSumStride];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (int k = 0; k < kSumStride; ++k) acc[k] = 0.0;
+    double rpart = 0.0;
     int cnt = 0;
     for (int i = lane; i < S; i += kWave) {
         if (!a.mem[i]) continue;
         const double* f = fit + (size_t)i * kFitStride;
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] += f[k];
+        acc[9] += f[12];
+        rpart += f[13];
         cnt++;
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = wave_sum_f64(acc[k]);  // exact integers: order-free
+    for (int k = 0; k < kSumStride; ++k) acc[k] = wave_sum_f64(acc[k]);  // exact integers: order-free
+    const double R = wave_sum_f64(rpart);                                 // wave order by id
     cnt = wave_sum_i32(cnt);
-    Sym3 A = { acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] };
-    Vec3 r = { acc[6], acc[7], acc[8] }, x = { 0, 0, 0 }, d = { 1, 1, 1 };
+    Vec3 x = { 0, 0, 0 };
     double p = 0.0, err = 0.0;
     int inf_flag = 0;
-    if (cnt > 0) {
-        ldl3(A, r, x, d);
-        double part = 0.0;
-        for (int i = lane; i < S; i += kWave) {
-            if (!a.mem[i]) continue;
-            part += member_quad(fit + (size_t)i * kFitStride, x);
-        }
-        err = wave_sum_f64(part) / (2.0 * a.var);
-        p = segment_logprob(err, d, det_log(a.var), &inf_flag);
-    }
+    if (cnt > 0) p = segment_from_sums(acc, R, a.var, det_log(a.var), x, err, &inf_flag);
     if (lane == 0) {
         a.out[0] = p; a.out[1] = err; a.out[2] = x.x; a.out[3] = x.y; a.out[4] = x.z;
         a.out[5] = inf_flag ? 1.0 : 0.0;

@@ -5,6 +5,8 @@
 
 namespace mc {
 
+constexpr int kSegCacheStride = 12;
+
 struct MomentArgs {
     const int16_t* disp;       // [F][H][W]
     const uint16_t* label;     // [F][H][W]
@@ -60,6 +62,7 @@ struct ChainArgs {
     double var, new_seg_prob;
     uint16_t* label;           // [C][s_max] min-id labels
     double* segP;              // [C][s_max]
+    double* segC;              // [C][s_max][kSegCacheStride] sums of the segment named by the row: 10 exact sums, sum of ssr, pad
     uint16_t* segN;            // [C][s_max]
     double* energy; double* best_energy;
     uint16_t* best_label; uint16_t* top_label;

@@ -187,7 +187,7 @@ class Context:
 
     def local_fit(self, frame):
         S = self.S[frame]
-        fit = np.zeros((S, 12)); valid = np.zeros(S, np.uint8); lerr = np.zeros(S)
+        fit = np.zeros((S, 16)); valid = np.zeros(S, np.uint8); lerr = np.zeros(S)
         self._ck(self.L.mcmc_frame_get_local_fit(self.h, frame, _ptr(fit, np.float64), _ptr(valid, np.uint8),
                                                  _ptr(lerr, np.float64)))
         return fit, valid, lerr

@@ -33,7 +33,7 @@
 
 #define ORC_NLANE 64
 #define ORC_NOLABEL 0xFFFFu
-#define ORC_FIT_STRIDE 12
+#define ORC_FIT_STRIDE 16
 #define ORC_MOM_STRIDE 10
 
 /* status codes shared with include/mcmc_amd.h by value */
@@ -74,24 +74,29 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 /*
- * Two families of draws per step, both counter-addressed:
- *  - the step's scalar draws, in the reference's rand() call order: start
- *    index, the discarded uniform, selectSegment's two, the MH uniform.  Draw d
- *    is word (d>>6)&3 of Philox block (d>>8)*64 + (d&63) (one block per lane of
- *    a 64-wide wavefront).
- *  - the Swendsen-Wang edge trials of createComponent: the trial of CSR entry e
- *    (neighbour col[e] tried from the popped node that owns row entry e) uses
- *    word e&3 of block 0x80000000 | (e>>2).  The reference hands its trials
- *    whatever rand() returns next; giving every trial its own counter keeps
- *    them independent uniforms (each directed entry is tried at most once per
- *    step) and removes the only sequential dependency of the growth, so the GPU
- *    can try 64 entries of several FIFO nodes at once.  The component, the FIFO
- *    order and every later decision are unchanged functions of those uniforms.
+ * Draws of one step are counter-addressed by a position p: the uniform at position
+ * p is word (p>>6)&3 of Philox block (p>>8)*64 + (p&63), i.e. 64 lanes of a
+ * wavefront generate positions [256 b, 256 b + 256) with one Philox call each.
+ *   p = 0  start index      (rand()%S,            Segmentation.cpp:155)
+ *   p = 1  discarded draw   (                     Segmentation.cpp:161)
+ *   p = 2  selectSegment's uniform                (Segmentation.cpp:23)
+ *   p = 3  selectSegment's index                  (Segmentation.cpp:40)
+ *   p = 4  the Metropolis-Hastings uniform        (MCMC.h:223)
+ *   p = 8 + n  the Swendsen-Wang trial of the n-th CSR entry examined by
+ *          createComponent (n counts every entry of every popped node in FIFO
+ *          order, whether or not it needs a trial).
+ * The reference hands a trial whatever rand() returns next, which makes the draw a
+ * trial gets depend on how many trials happened before it.  Numbering by examined
+ * entry keeps the trials independent uniforms in sequential order (an entry is
+ * examined at most once per step) but makes the position of a trial a prefix sum of
+ * node degrees, so the GPU can try 64 entries of several FIFO nodes in one pass and
+ * serve four passes from one Philox call.  The component, the FIFO order and every
+ * later decision are unchanged functions of those uniforms.
  */
+#define ORC_TRIAL_POS0 8u
 typedef struct {
     uint32_t key[2];
     uint32_t step_lo, step_hi;
-    uint32_t ndraw;       /* draws consumed this step */
     uint32_t cur_batch;   /* batch cached in buf */
     uint8_t have[64];
     uint32_t buf[64][4];
@@ -101,13 +106,12 @@ static void rng_begin(orc_rng *g, uint32_t seed, uint32_t chain, uint64_t step)
 {
     g->key[0] = seed; g->key[1] = chain;
     g->step_lo = (uint32_t)step; g->step_hi = (uint32_t)(step >> 32);
-    g->ndraw = 0; g->cur_batch = 0xFFFFFFFFu;
+    g->cur_batch = 0xFFFFFFFFu;
 }
 
-static uint32_t rng_u32(orc_rng *g)
+static uint32_t rng_u32_at(orc_rng *g, uint32_t p)
 {
-    uint32_t d = g->ndraw++;
-    uint32_t batch = d >> 8, lane = d & 63u, w = (d >> 6) & 3u;
+    uint32_t batch = p >> 8, lane = p & 63u, w = (p >> 6) & 3u;
     if (batch != g->cur_batch) { memset(g->have, 0, sizeof g->have); g->cur_batch = batch; }
     if (!g->have[lane]) {
         uint32_t ctr[4] = { g->step_lo, g->step_hi, batch * 64u + lane, PHILOX_TAG };
@@ -117,18 +121,10 @@ static uint32_t rng_u32(orc_rng *g)
     return g->buf[lane][w];
 }
 
-/* uniform of the edge trial of CSR entry e */
-static double rng_entry_unif(const orc_rng *g, uint32_t e)
-{
-    uint32_t ctr[4] = { g->step_lo, g->step_hi, 0x80000000u | (e >> 2), PHILOX_TAG }, out[4];
-    orc_philox4x32_10(ctr, g->key, out);
-    return (double)out[e & 3u] / 4294967295.0;
-}
-
 /* rand()/RAND_MAX is inclusive of 1.0 (MCMC.h:223, Segmentation.cpp:23,109). */
-static double rng_unif(orc_rng *g)
+static double rng_unif_at(orc_rng *g, uint32_t p)
 {
-    return (double)rng_u32(g) / 4294967295.0;
+    return (double)rng_u32_at(g, p) / 4294967295.0;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -265,9 +261,11 @@ int orc_moments(const int16_t *disp, const uint16_t *label, int W, int H, int S,
 
 /* 3x3 SPD solve by LDL^T without pivoting, fixed evaluation order.  Stands   */
 /* in for gtsam's QR elimination (MyMath.h:141-143, 238-240); same solution   */
-/* of the same normal equations.  Returns pivots in d[3].                      */
-static void ldl3(const double a[6] /* a11 a12 a22 a13 a23 a33 */, const double r[3],
-                 double x[3], double d[3])
+/* of the same normal equations.  Returns pivots in d[3] and r' A^-1 r from    */
+/* the factorisation (sum y_k^2 / d_k), which is how the residual of the fit   */
+/* is obtained without a pass over the data: |A x - b|^2 = b'b - r' A^-1 r.    */
+static double ldl3(const double a[6] /* a11 a12 a22 a13 a23 a33 */, const double r[3],
+                   double x[3], double d[3])
 {
     double a11 = a[0], a12 = a[1], a22 = a[2], a13 = a[3], a23 = a[4], a33 = a[5];
     double d1 = a11;
@@ -286,6 +284,7 @@ static void ldl3(const double a[6] /* a11 a12 a22 a13 a23 a33 */, const double r
     double x1 = (z1 - l21 * x2) - l31 * x3;
     x[0] = x1; x[1] = x2; x[2] = x3;
     d[0] = d1; d[1] = d2; d[2] = d3;
+    return (y1 * z1 + y2 * z2) + y3 * z3;
 }
 
 /*
@@ -293,9 +292,10 @@ static void ldl3(const double a[6] /* a11 a12 a22 a13 a23 a33 */, const double r
  * 422-455).  Coordinates are shifted to the frame centre (cx=W/2, cy=H/2) in
  * exact integer arithmetic before going to double: energies are invariant
  * under the shift (unimodular change of basis), conditioning improves ~1e5x.
- * fit record (12 doubles): Suu Suv Svv Su Sv N | Sub Svb Sb | theta_a theta_b theta_c
- * theta is in centred coordinates: disparity = a*(u-cx) + b*(v-cy) + c.
- * local_err = 1/2 |A theta - b|^2 / var (MyMath.h:146-150), informational.
+ * fit record (16 doubles): Suu Suv Svv Su Sv N | Sub Svb Sb | theta_a theta_b theta_c |
+ * Sbb ssr 0 0.  theta is in centred coordinates: disparity = a*(u-cx) + b*(v-cy) + c.
+ * ssr = |A theta - b|^2 = Sbb - r' A^-1 r (from the factorisation);
+ * local_err = ssr / (2 var) (MyMath.h:146-150).
  */
 int orc_local_fit(const int64_t *mom, int W, int H, int S, double var,
                   double *fit, uint8_t *valid, double *local_err)
@@ -324,16 +324,15 @@ int orc_local_fit(const int64_t *mom, int W, int H, int S, double var,
             double a[6] = { f[0], f[1], f[2], f[3], f[4], f[5] };
             double r[3] = { f[6], f[7], f[8] };
             double x[3], d[3];
-            ldl3(a, r, x, d);
+            double quad = ldl3(a, r, x, d);
             f[9] = x[0]; f[10] = x[1]; f[11] = x[2];
-            if (local_err) {
-                double sse = (double)m[9] - ((x[0] * r[0] + x[1] * r[1]) + x[2] * r[2]);
-                local_err[s] = sse / (2.0 * var);
-            }
+            f[12] = (double)m[9]; f[13] = f[12] - quad;
         } else {
             f[9] = f[10] = f[11] = 0.0;
-            if (local_err) local_err[s] = 0.0;
+            f[12] = (double)m[9]; f[13] = 0.0;
         }
+        f[14] = f[15] = 0.0;
+        if (local_err) local_err[s] = f[13] / (2.0 * var);
     }
     return ORC_OK;
 }
@@ -342,54 +341,69 @@ int orc_local_fit(const int64_t *mom, int W, int H, int S, double var,
 
 /*
  * A3/A4: fit() (MyMath.h:189-275) + Segment::fitGlobalSurface/computeProbability
- * (Graph.cpp:69-138).  mem[i]==which selects the members.  Information-form
- * fusion: M = sum M_i, m = sum m_i (exact: integer-valued doubles),
- * theta = M^-1 m; totalError = sum_i 1/2 (theta-theta_i)' M_i (theta-theta_i)/var
- * (the factor errors of MyMath.h:247-252; local error_ is NOT added,
- * Graph.cpp:101); probabilityL = -error + log sqrt det(2 pi Lambda^-1).
+ * (Graph.cpp:69-138).  Information-form fusion: M = sum M_i, m = sum m_i (exact:
+ * integer-valued doubles), theta = M^-1 m.  totalError is the sum of the member
+ * factors' errors at the fused mean, sum_i 1/2 (theta-theta_i)' M_i (theta-theta_i) / var
+ * (MyMath.h:247-252; the members' local error_ is NOT added, Graph.cpp:101).  Each
+ * term is the member's residual at theta minus its own least-squares residual, so
+ *     2 var * totalError = (Sbb - m' M^-1 m) - sum_i ssr_i
+ * with Sbb = sum_i Sbb_i exact.  This form needs only sums over the members, which
+ * is what lets a proposal be evaluated from the cached sums of the two segments and
+ * the sums over the component: sB2 = sA2 + C, sB1 = sA1 - C.
+ * probabilityL = -error + log sqrt det(2 pi Lambda^-1).
  * Quirk kept: NaN -> 0.75 (Graph.cpp:134); +-inf -> status (Graph.cpp:137).
  */
+#define ORC_SUM_STRIDE 10   /* Suu Suv Svv Su Sv N Sub Svb Sb Sbb */
 typedef struct {
     double probL, err, theta[3], logdet;
+    double m[ORC_SUM_STRIDE], R;  /* the sums the result was computed from */
     int n, minid, status;
 } orc_segfit;
 
-static void seg_eval(const double *fit, int S, const uint8_t *mem, uint8_t which,
-                     double var, double log_var, orc_segfit *out)
+/* probabilityL from the segment's sums: m[10] exact, R = sum of member ssr */
+static void seg_finish(const double *m, double R, double var, double log_var, orc_segfit *out)
 {
-    double a[6] = { 0, 0, 0, 0, 0, 0 }, r[3] = { 0, 0, 0 };
-    int n = 0, minid = -1;
-    for (int i = 0; i < S; ++i) {
-        if (mem[i] != which) continue;
-        const double *f = fit + (size_t)i * ORC_FIT_STRIDE;
-        a[0] += f[0]; a[1] += f[1]; a[2] += f[2]; a[3] += f[3]; a[4] += f[4]; a[5] += f[5];
-        r[0] += f[6]; r[1] += f[7]; r[2] += f[8];
-        if (minid < 0) minid = i;
-        n++;
-    }
-    out->n = n; out->minid = minid; out->status = ORC_OK;
-    if (n == 0) { out->probL = 0.0; out->err = 0.0; out->logdet = 0.0;
-                  out->theta[0] = out->theta[1] = out->theta[2] = 0.0; return; }
     double x[3], d[3];
-    ldl3(a, r, x, d);
-    double part[ORC_NLANE];
-    for (int l = 0; l < ORC_NLANE; ++l) part[l] = 0.0;
-    for (int i = 0; i < S; ++i) {
-        if (mem[i] != which) continue;
-        const double *f = fit + (size_t)i * ORC_FIT_STRIDE;
-        double da = x[0] - f[9], db = x[1] - f[10], dc = x[2] - f[11];
-        double e = da * ((f[0] * da + f[1] * db) + f[3] * dc)
-                 + db * ((f[1] * da + f[2] * db) + f[4] * dc)
-                 + dc * ((f[3] * da + f[4] * db) + f[5] * dc);
-        part[i & (ORC_NLANE - 1)] += e;
-    }
-    double err = wave_sum(part) / (2.0 * var);
+    double quad = ldl3(m, m + 6, x, d);
+    double err = ((m[9] - quad) - R) / (2.0 * var);
     double logdet = ((orc_det_log(d[0]) + orc_det_log(d[1])) + orc_det_log(d[2])) - 3.0 * log_var;
     double p = -err + 0.5 * (3.0 * LOG_2PI - logdet);
+    out->status = ORC_OK;
     if (p != p) p = 0.75;
     if (p - p != 0.0) out->status = ORC_E_INF_ENERGY;
     out->probL = p; out->err = err; out->logdet = logdet;
     out->theta[0] = x[0]; out->theta[1] = x[1]; out->theta[2] = x[2];
+    for (int k = 0; k < ORC_SUM_STRIDE; ++k) out->m[k] = m[k];
+    out->R = R;
+}
+
+static inline void rec_sums(const double *f, double *m)
+{
+    for (int k = 0; k < 9; ++k) m[k] += f[k];
+    m[9] += f[12];
+}
+
+/* from scratch: mem[i]==which selects the members; R in wave order by id */
+static void seg_eval(const double *fit, int S, const uint8_t *mem, uint8_t which,
+                     double var, double log_var, orc_segfit *out)
+{
+    double m[ORC_SUM_STRIDE] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    double part[ORC_NLANE];
+    for (int l = 0; l < ORC_NLANE; ++l) part[l] = 0.0;
+    int n = 0, minid = -1;
+    for (int i = 0; i < S; ++i) {
+        if (mem[i] != which) continue;
+        const double *f = fit + (size_t)i * ORC_FIT_STRIDE;
+        rec_sums(f, m);
+        part[i & (ORC_NLANE - 1)] += f[13];
+        if (minid < 0) minid = i;
+        n++;
+    }
+    memset(out, 0, sizeof *out);
+    out->n = n; out->minid = minid; out->status = ORC_OK;
+    if (n == 0) return;
+    seg_finish(m, wave_sum(part), var, log_var, out);
+    out->n = n; out->minid = minid;
 }
 
 /* public wrapper: members given as an id list */
@@ -481,6 +495,8 @@ typedef struct orc_chains {
     uint16_t *label;     /* n_chains*S, min-id labels */
     double *segP;        /* n_chains*S, probabilityL_ by root label */
     uint32_t *segN;      /* n_chains*S, sizes by root label */
+    double *segM;        /* n_chains*S*10, the segment's exact sums by root label */
+    double *segR;        /* n_chains*S, sum of the members' ssr by root label */
     double *energy;      /* running sum of probabilityL_ (Segmentation::computeProbability) */
     double *best_energy; uint16_t *best_label;
     uint64_t *state_hash, *trace_hash;
@@ -517,7 +533,7 @@ static void canonical_labels(const uint16_t *label, const uint8_t *valid, int S,
 void orc_chains_free(orc_chains *c)
 {
     if (!c) return;
-    free(c->vlist); free(c->label); free(c->segP); free(c->segN); free(c->energy);
+    free(c->vlist); free(c->label); free(c->segP); free(c->segN); free(c->segM); free(c->segR); free(c->energy);
     free(c->best_energy); free(c->best_label); free(c->state_hash); free(c->trace_hash);
     free(c->n_accept); free(c->n_case); free(c->status); free(c->visits); free(c->n_visits);
     free(c->overflow); free(c->top_count); free(c->top_hash); free(c->top_label); free(c->marg);
@@ -542,6 +558,8 @@ orc_chains *orc_chains_create(int S, const double *fit, const uint8_t *valid,
     c->label = (uint16_t *)malloc(sizeof(uint16_t) * NS);
     c->segP = (double *)calloc(NS, sizeof(double));
     c->segN = (uint32_t *)calloc(NS, sizeof(uint32_t));
+    c->segM = (double *)calloc(NS * ORC_SUM_STRIDE, sizeof(double));
+    c->segR = (double *)calloc(NS, sizeof(double));
     c->energy = (double *)calloc((size_t)n_chains, sizeof(double));
     c->best_energy = (double *)calloc((size_t)n_chains, sizeof(double));
     c->best_label = (uint16_t *)malloc(sizeof(uint16_t) * NS);
@@ -574,6 +592,8 @@ orc_chains *orc_chains_create(int S, const double *fit, const uint8_t *valid,
         if (c->Sv) {
             c->segP[(size_t)k * S + root] = f0.probL;
             c->segN[(size_t)k * S + root] = (uint32_t)c->Sv;
+            memcpy(c->segM + ((size_t)k * S + root) * ORC_SUM_STRIDE, f0.m, sizeof f0.m);
+            c->segR[(size_t)k * S + root] = f0.R;
         }
         c->energy[k] = f0.probL;
         c->best_energy[k] = f0.probL;
@@ -640,22 +660,25 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
     rng_begin(&g, c->seed, c->chain_offset + (uint32_t)k, t);
 
     /* pickSuperPixel (Segmentation.cpp:151-183): rand()%S then one unused draw */
-    uint32_t start = c->vlist[rng_u32(&g) % (uint32_t)c->Sv];
-    (void)rng_u32(&g);
+    uint32_t start = c->vlist[rng_u32_at(&g, 0) % (uint32_t)c->Sv];
+    const double u1 = rng_unif_at(&g, 2);        /* Segmentation.cpp:23 */
+    const uint32_t idx_draw = rng_u32_at(&g, 3); /* Segmentation.cpp:40 (used only on that branch) */
+    const double r_mh = rng_unif_at(&g, 4);      /* MCMC.h:223, always drawn */
     const uint16_t orig = lab[start];
 
     /* createComponent BFS (Segmentation.cpp:74-120) */
-    uint32_t qn = 0;
+    uint32_t qn = 0, npos = ORC_TRIAL_POS0;
     c->queue[qn++] = start; c->inC[start] = 1;
     for (uint32_t head = 0; head < qn; ++head) {
         uint32_t i = c->queue[head];
         for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e) {
+            const uint32_t p = npos++;            /* position of this entry in the examined stream */
             double qe = c->q[e];
             if (qe < 0.0) continue;               /* not an edge in the reference graph */
             uint32_t j = c->col[e];
             if (c->inC[j]) continue;              /* :94 already in component */
             if (lab[j] != orig) { c->nbr[lab[j]] = 1; continue; } /* :100-105 */
-            double r = rng_entry_unif(&g, e);     /* :109 */
+            double r = rng_unif_at(&g, p);        /* :109 */
             if (r < qe) { c->inC[j] = 1; c->queue[qn++] = j; } /* :110-117, strict */
         }
     }
@@ -663,7 +686,6 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
     const int same = (csize == segN[orig]);      /* Segmentation.cpp:19 */
 
     /* selectSegment (Segmentation.cpp:10-57) */
-    double u1 = rng_unif(&g);                    /* :23 */
     int kase; uint16_t next = orig; double ratio;
     uint32_t nn = 0;
     for (int i = 0; i < S; ++i) nn += c->nbr[i];
@@ -672,7 +694,7 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
     } else {
         double existing = same ? 1.0 : (1.0 - c->new_seg_prob); /* :36 */
         uint32_t numSeg = nn + 1;                /* :39 */
-        uint32_t idx = rng_u32(&g) % numSeg;     /* :40 */
+        uint32_t idx = idx_draw % numSeg;        /* :40 */
         if (idx == numSeg - 1) { next = orig; kase = 0; } /* :43-45 */
         else {
             uint32_t seen = 0; kase = 2;
@@ -684,20 +706,27 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
 
     double targetL, prop;
     orc_segfit fB1, fB2;
-    fB1.n = 0; fB1.probL = 0.0; fB1.minid = -1; fB1.status = 0;
-    fB2.n = 0; fB2.probL = 0.0; fB2.minid = -1; fB2.status = 0;
+    memset(&fB1, 0, sizeof fB1); memset(&fB2, 0, sizeof fB2);
+    fB1.minid = -1; fB2.minid = -1;
     int st = ORC_OK;
+    const int have1 = !same;                     /* sB1 = sA1 \ C is not empty */
     if (kase == 0) {
         /* Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic, it is used as a log) */
         prop = ratio; targetL = 1.0;
     } else {
-        /* separation / merge products (Segmentation.cpp:127-146, Graph.cpp:10-33),
-         * wave order over the BFS queue */
-        double psep[ORC_NLANE], pmrg[ORC_NLANE];
-        for (int l = 0; l < ORC_NLANE; ++l) { psep[l] = 1.0; pmrg[l] = 1.0; }
+        /* separation / merge products (Segmentation.cpp:127-146, Graph.cpp:10-33) and the
+         * component's sums, wave order over the BFS queue */
+        double psep[ORC_NLANE], pmrg[ORC_NLANE], rpart[ORC_NLANE];
+        double Mc[ORC_SUM_STRIDE] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        int minC = S;
+        for (int l = 0; l < ORC_NLANE; ++l) { psep[l] = 1.0; pmrg[l] = 1.0; rpart[l] = 0.0; }
         for (uint32_t h = 0; h < qn; ++h) {
             uint32_t i = c->queue[h];
             int l = (int)(h & (ORC_NLANE - 1));
+            const double *f = c->fit + (size_t)i * ORC_FIT_STRIDE;
+            rec_sums(f, Mc);
+            rpart[l] += f[13];
+            if ((int)i < minC) minC = (int)i;
             for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e) {
                 double qe = c->q[e];
                 if (qe < 0.0) continue;
@@ -707,14 +736,25 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
             }
         }
         double sep = wave_prod(psep);
-        for (int i = 0; i < S; ++i) {
-            uint8_t m = 0;
-            if (kase == 1) m = c->inC[i] ? 2 : (lab[i] == orig ? 1 : 0);
-            else m = (c->inC[i] || lab[i] == next) ? 2 : ((lab[i] == orig && !same) ? 1 : 0);
-            c->mem[i] = c->valid[i] ? m : 0;
+        const double Rc = wave_sum(rpart);
+        /* Segment::combine / diff (Graph.cpp:35-67) on the cached sums instead of a refit from the
+         * member list: sB2 = sA2 + C (or C alone for a new segment), sB1 = sA1 - C */
+        double M2[ORC_SUM_STRIDE], M1[ORC_SUM_STRIDE], R2, R1 = 0.0;
+        const double *Mo = c->segM + ((size_t)k * S + orig) * ORC_SUM_STRIDE;
+        const double *Mn = c->segM + ((size_t)k * S + next) * ORC_SUM_STRIDE;
+        for (int v = 0; v < ORC_SUM_STRIDE; ++v) {
+            M2[v] = kase == 2 ? Mn[v] + Mc[v] : Mc[v];
+            M1[v] = Mo[v] - Mc[v];
         }
-        seg_eval(c->fit, S, c->mem, 2, c->var, c->log_var, &fB2);
-        if (!(kase == 2 && same)) seg_eval(c->fit, S, c->mem, 1, c->var, c->log_var, &fB1);
+        R2 = kase == 2 ? c->segR[(size_t)k * S + next] + Rc : Rc;
+        seg_finish(M2, R2, c->var, c->log_var, &fB2);
+        fB2.n = (int)csize + (kase == 2 ? (int)segN[next] : 0);
+        fB2.minid = (kase == 2 && (int)next < minC) ? (int)next : minC;
+        if (have1) {
+            R1 = c->segR[(size_t)k * S + orig] - Rc;
+            seg_finish(M1, R1, c->var, c->log_var, &fB1);
+            fB1.n = (int)segN[orig] - (int)csize;
+        }
         if (kase == 1) {
             prop = ratio * (1.0 / sep);          /* Problem.cpp:188 */
         } else {
@@ -723,7 +763,7 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
         }
         /* jumpProbability (Problem.cpp:475-487) */
         double sB2_sA1 = fB2.probL - segP[orig];
-        double sB1_sA2 = ((kase == 2 && same) ? 0.0 : fB1.probL) - (kase == 2 ? segP[next] : 0.0);
+        double sB1_sA2 = (have1 ? fB1.probL : 0.0) - (kase == 2 ? segP[next] : 0.0);
         targetL = sB2_sA1 + sB1_sA2;
         if (fB1.status) st = fB1.status;
         if (fB2.status) st = fB2.status;
@@ -733,7 +773,7 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
     /* FastMetropolisHastings::iterate (MCMC.h:218-227) */
     double aL = targetL + orc_det_log(prop);
     double a = orc_det_exp(aL);
-    double r = rng_unif(&g);                     /* always drawn */
+    const double r = r_mh;
     int accept = 1;
     if (aL < 0.0) { if (r > a) accept = 0; }
     if (st != ORC_OK) { accept = 0; c->status[k] = st; }
@@ -741,14 +781,26 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
     uint16_t newlab = next;
     if (accept && kase != 0) {
         /* jump (Problem.cpp:32-74) with min-id naming */
-        uint16_t L2 = (uint16_t)fB2.minid;
-        uint16_t L1 = (uint16_t)(fB1.n ? fB1.minid : 0);
+        uint16_t L2 = (uint16_t)fB2.minid, L1 = 0;
+        if (have1) {
+            /* smallest id left in the old segment */
+            int m1 = orig;
+            if (c->inC[orig]) { m1 = -1; for (int i = 0; i < S && m1 < 0; ++i) if (lab[i] == orig && !c->inC[i]) m1 = i; }
+            fB1.minid = m1; L1 = (uint16_t)m1;
+        }
         for (int i = 0; i < S; ++i) {
-            if (c->mem[i] == 2) lab[i] = L2;
-            else if (c->mem[i] == 1) lab[i] = L1;
+            if (!c->valid[i]) continue;
+            if (c->inC[i] || (kase == 2 && lab[i] == next)) lab[i] = L2;
+            else if (have1 && lab[i] == orig) lab[i] = L1;
         }
         segP[L2] = fB2.probL; segN[L2] = (uint32_t)fB2.n;
-        if (fB1.n) { segP[L1] = fB1.probL; segN[L1] = (uint32_t)fB1.n; }
+        memcpy(c->segM + ((size_t)k * S + L2) * ORC_SUM_STRIDE, fB2.m, sizeof fB2.m);
+        c->segR[(size_t)k * S + L2] = fB2.R;
+        if (have1) {
+            segP[L1] = fB1.probL; segN[L1] = (uint32_t)fB1.n;
+            memcpy(c->segM + ((size_t)k * S + L1) * ORC_SUM_STRIDE, fB1.m, sizeof fB1.m);
+            c->segR[(size_t)k * S + L1] = fB1.R;
+        }
         c->energy[k] += targetL;
         c->state_hash[k] = state_hash_of(lab, c->valid, S);
         if (c->energy[k] > c->best_energy[k]) {
@@ -763,7 +815,6 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
     /* clear scratch */
     for (uint32_t h = 0; h < qn; ++h) c->inC[c->queue[h]] = 0;
     memset(c->nbr, 0, (size_t)S);
-    memset(c->mem, 0, (size_t)S);
 
     uint8_t tb = (uint8_t)(accept | (kase << 1));
     uint64_t w = (uint64_t)tb | ((uint64_t)start << 8) | ((uint64_t)csize << 24) | ((uint64_t)newlab << 40);

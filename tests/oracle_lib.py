@@ -91,7 +91,7 @@ def moments(disp, label, S):
 
 def local_fit(mom, W, H, var=7.0):
     S = mom.shape[0]
-    fit = np.zeros((S, 12), np.float64)
+    fit = np.zeros((S, 16), np.float64)
     valid = np.zeros(S, np.uint8)
     lerr = np.zeros(S, np.float64)
     lib().orc_local_fit(np.ascontiguousarray(mom), W, H, S, var, fit, valid, lerr)

@@ -20,8 +20,8 @@ ctx.chains_run(0, iters)
 ms = ctx.last_kernel_ms(3)
 pp = ctx.chain_profile().astype(np.float64) / (n * iters)
 p = pp[:12]
-print("mean component size %.1f  draws/step %.1f  refit members/step %.1f" % (pp[12], pp[13], pp[14]))
-names = ["pick", "bfs", "select", "products", "pass1+reduce", "solve", "pass2", "reduce2+logprob", "mh", "flush_stats",
+print("mean component size %.1f  stream positions/step %.1f  refit members/step %.1f  bfs passes/step %.2f" % (pp[12], pp[13], pp[14], pp[15]))
+names = ["pick", "bfs", "select", "products+sums", "reductions", "two fits", "ratios", "(unused)", "mh", "flush_stats",
          "apply", "bookkeeping"]
 print(f"plain {base_ms*1e3/iters:.2f} us/step   profiled {ms*1e3/iters:.2f} us/step   cycles/step {p.sum():.0f}")
 for k, v in zip(names, p):
