@@ -27,8 +27,8 @@ struct Chains {
     int n = 0, cpf = 0;
     uint32_t seed = 0, offset = 0;
     unsigned long long step = 0;
-    uint16_t *label = nullptr, *segN = nullptr, *best_label = nullptr, *top_label = nullptr, *canon = nullptr;
-    double *segP = nullptr, *segC = nullptr, *energy = nullptr, *best_energy = nullptr, *tmp_energy = nullptr;
+    uint16_t *label = nullptr, *best_label = nullptr, *top_label = nullptr, *canon = nullptr;
+    double *segC = nullptr, *energy = nullptr, *best_energy = nullptr, *tmp_energy = nullptr;
     unsigned long long *state_hash = nullptr, *trace_hash = nullptr, *n_accept = nullptr, *n_case = nullptr;
     unsigned long long *visit_hash = nullptr, *visit_count = nullptr, *overflow = nullptr, *top_count = nullptr,
                        *top_hash = nullptr;
@@ -98,8 +98,8 @@ void dfree(T*& p)
 
 void free_chains(Chains& h)
 {
-    dfree(h.label); dfree(h.segN); dfree(h.best_label); dfree(h.top_label); dfree(h.canon);
-    dfree(h.segP); dfree(h.segC); dfree(h.energy); dfree(h.best_energy); dfree(h.tmp_energy);
+    dfree(h.label); dfree(h.best_label); dfree(h.top_label); dfree(h.canon);
+    dfree(h.segC); dfree(h.energy); dfree(h.best_energy); dfree(h.tmp_energy);
     dfree(h.state_hash); dfree(h.trace_hash); dfree(h.n_accept); dfree(h.n_case);
     dfree(h.visit_hash); dfree(h.visit_count); dfree(h.overflow); dfree(h.top_count); dfree(h.top_hash);
     dfree(h.status); dfree(h.trace);
@@ -129,7 +129,7 @@ ChainArgs chain_args(mcmc_ctx* c)
     a.S = c->d_S; a.E2 = c->d_E2; a.s_max = c->s_max; a.e2_max = c->e2_max;
     a.n_chains = c->ch.n; a.chains_per_frame = c->ch.cpf; a.seed = c->ch.seed; a.chain_offset = c->ch.offset;
     a.var = c->p.disparity_variance; a.new_seg_prob = c->p.new_segment_prob;
-    a.label = c->ch.label; a.segP = c->ch.segP; a.segC = c->ch.segC; a.segN = c->ch.segN;
+    a.label = c->ch.label; a.segC = c->ch.segC;
     a.energy = c->ch.energy; a.best_energy = c->ch.best_energy;
     a.best_label = c->ch.best_label; a.top_label = c->ch.top_label;
     a.state_hash = c->ch.state_hash; a.trace_hash = c->ch.trace_hash;
@@ -495,8 +495,8 @@ int mcmc_chains_init(mcmc_ctx* c, int n_chains, int cpf, uint32_t seed, uint32_t
     Chains& h = c->ch;
     h.n = n_chains; h.cpf = cpf; h.seed = seed; h.offset = chain_offset; h.step = 0;
     const size_t N = (size_t)n_chains, NS = N * (size_t)c->s_max, NH = N * (size_t)c->p.visit_capacity;
-    HIPCHK(c, dalloc(&h.label, NS)); HIPCHK(c, dalloc(&h.segN, NS)); HIPCHK(c, dalloc(&h.best_label, NS));
-    HIPCHK(c, dalloc(&h.top_label, NS)); HIPCHK(c, dalloc(&h.canon, NS)); HIPCHK(c, dalloc(&h.segP, NS)); HIPCHK(c, dalloc(&h.segC, NS * mc::kSegCacheStride));
+    HIPCHK(c, dalloc(&h.label, NS)); HIPCHK(c, dalloc(&h.best_label, NS));
+    HIPCHK(c, dalloc(&h.top_label, NS)); HIPCHK(c, dalloc(&h.canon, NS)); HIPCHK(c, dalloc(&h.segC, NS * mc::kSegCacheStride));
     HIPCHK(c, dalloc(&h.energy, N)); HIPCHK(c, dalloc(&h.best_energy, N)); HIPCHK(c, dalloc(&h.tmp_energy, N));
     HIPCHK(c, dalloc(&h.state_hash, N)); HIPCHK(c, dalloc(&h.trace_hash, N)); HIPCHK(c, dalloc(&h.n_accept, N));
     HIPCHK(c, dalloc(&h.n_case, N * 3)); HIPCHK(c, dalloc(&h.visit_hash, NH)); HIPCHK(c, dalloc(&h.visit_count, NH));

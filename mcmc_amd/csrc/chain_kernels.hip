@@ -21,6 +21,8 @@
 // Canonical order (the reference iterates std::set/std::map in heap-pointer
 // order, i.e. arbitrarily): superpixels by id; a segment is named by its
 // smallest member id.
+#include <type_traits>
+
 #include "device_math.hpp"
 #include "kernels.hpp"
 
@@ -39,76 +41,43 @@ static inline size_t h_al16(size_t x) { return (x + 15) & ~(size_t)15; }
 // p = 8 + n: trial of the n-th CSR entry examined by the component growth.
 constexpr uint32_t kTrialPos0 = 8u;
 struct Rng {
-    uint32_t w0;                  // raw word 0 (integer draws of positions 0..63)
-    double r0, r1, r2, r3;        // the draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
     uint32_t k0, k1, step_lo, step_hi;
     int batch;
+    double* buf;                  // LDS, [4][64]: the batch's draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
 };
 
 MC_D double to_unit(uint32_t x) { return (double)x / 4294967295.0; }
+MC_D void wave_fence();
 
-MC_D void rng_gen(Rng& g, int batch, int lane)
+// generates positions [256 batch, 256 batch + 256) into g.buf; returns the lane's raw words
+MC_D u32x4 rng_gen(Rng& g, int batch, int lane)
 {
     u32x4 c = { g.step_lo, g.step_hi, (uint32_t)(batch * 64 + lane), kPhiloxTag };
     u32x4 r = philox4x32_10(c, g.k0, g.k1);
-    g.w0 = r.x;
+    wave_fence();
     // the divisions are done once per 256 positions, off the BFS critical path
-    g.r0 = to_unit(r.x); g.r1 = to_unit(r.y); g.r2 = to_unit(r.z); g.r3 = to_unit(r.w);
+    g.buf[lane] = to_unit(r.x); g.buf[64 + lane] = to_unit(r.y);
+    g.buf[128 + lane] = to_unit(r.z); g.buf[192 + lane] = to_unit(r.w);
+    wave_fence();
     g.batch = batch;
+    return r;
 }
 
-// Uniforms of positions p0 + lane (p0 wave-uniform) for the lanes that `need` one.  Position p lives in
-// lane p & 63 of its batch, and the 64 consecutive positions of a pass hit every source lane once, so a
-// source lane knows its one consumer, picks the word that consumer wants, and the consumer pulls it.
-MC_D double rng_trial(Rng& g, uint32_t p0, bool need, int lane)
+// Uniforms of positions p0 + lane, lane < count (p0, count wave-uniform): position p sits at
+// buf[(p >> 6) & 3][p & 63] of its batch.
+MC_D double rng_trial(Rng& g, uint32_t p0, uint32_t count, int lane)
 {
     const uint32_t p = p0 + (uint32_t)lane;
-    const uint32_t pc = p0 + (((uint32_t)lane - p0) & 63u);   // position this lane serves
-    const uint32_t ws = (pc >> 6) & 3u;
+    const uint32_t slot = p & 255u;
     const int b0 = (int)(p0 >> 8);
     if (b0 != g.batch) rng_gen(g, b0, lane);
-    double sel = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
-    double res = __shfl(sel, (int)(p & 63u), kWave);
-    if (__ballot(need && (int)(p >> 8) != b0)) {              // the pass crosses into the next 256 positions
+    double res = g.buf[slot];
+    if ((int)((p0 + count - 1u) >> 8) != b0) {                // the pass crosses into the next 256 positions
         rng_gen(g, b0 + 1, lane);
-        sel = ws == 0 ? g.r0 : (ws == 1 ? g.r1 : (ws == 2 ? g.r2 : g.r3));
-        const double v = __shfl(sel, (int)(p & 63u), kWave);
+        const double v = g.buf[slot];
         if ((int)(p >> 8) != b0) res = v;
     }
     return res;
-}
-
-// idx-th set flag (ascending) of a byte-flag array read as NWB 32-bit words (4 flags each,
-// every flag 0 or 1); wave-uniform result = the flag's index
-MC_D uint32_t nth_flag(const uint32_t* words, int NWB, uint32_t idx, int lane)
-{
-    uint32_t acc = 0, result = 0xFFFFFFFFu;
-    for (int wb = 0; wb < NWB; wb += kWave) {
-        const int w = wb + lane;
-        const uint32_t word = w < NWB ? words[w] : 0u;
-        const int pc = __popc(word);
-        int incl = pc;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const int t = __shfl_up(incl, off, kWave);
-            if (lane >= off) incl += t;
-        }
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-        if (idx < acc + total) {
-            const uint32_t rel = idx - acc;
-            const uint32_t excl = (uint32_t)(incl - pc);
-            const bool here = rel >= excl && rel < (uint32_t)incl;
-            uint32_t ww = word;
-            const uint32_t k = here ? rel - excl : 0u;
-            for (uint32_t t = 0; t < k; ++t) ww &= ww - 1u;
-            const uint32_t val = (uint32_t)w * 4u + ((uint32_t)(__ffs((int)ww) - 1) >> 3);
-            const uint64_t hm = __ballot(here);
-            result = (uint32_t)__builtin_amdgcn_readlane((int)val, __ffsll((unsigned long long)hm) - 1);
-            break;
-        }
-        acc += total;
-    }
-    return result;
 }
 
 // Lanes of one wave that exchange data through LDS: hardware runs a wave's LDS operations in order, the
@@ -142,6 +111,34 @@ MC_D uint32_t wave_scan_max_u32(uint32_t v)
     return v;
 }
 
+// idx-th set flag (ascending) of a byte-flag array read as NWB 32-bit words (4 flags each,
+// every flag 0 or 1); wave-uniform result = the flag's index
+MC_D uint32_t nth_flag(const uint32_t* words, int NWB, uint32_t idx, int lane)
+{
+    uint32_t acc = 0, result = 0xFFFFFFFFu;
+    for (int wb = 0; wb < NWB; wb += kWave) {
+        const int w = wb + lane;
+        const uint32_t word = w < NWB ? words[w] : 0u;
+        const int pc = __popc(word);
+        const int incl = (int)wave_scan_add_u32((uint32_t)pc);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+        if (idx < acc + total) {
+            const uint32_t rel = idx - acc;
+            const uint32_t excl = (uint32_t)(incl - pc);
+            const bool here = rel >= excl && rel < (uint32_t)incl;
+            uint32_t ww = word;
+            const uint32_t k = here ? rel - excl : 0u;
+            for (uint32_t t = 0; t < k; ++t) ww &= ww - 1u;
+            const uint32_t val = (uint32_t)w * 4u + ((uint32_t)(__ffs((int)ww) - 1) >> 3);
+            const uint64_t hm = __ballot(here);
+            result = (uint32_t)__builtin_amdgcn_readlane((int)val, __ffsll((unsigned long long)hm) - 1);
+            break;
+        }
+        acc += total;
+    }
+    return result;
+}
+
 // per-superpixel record of the chain kernel: the 10 exact sums and ssr (fit record entries 0..8, 12, 13)
 constexpr int kRecStride = 11;
 
@@ -155,10 +152,11 @@ struct SegFit {
 // ---------------------------------------------------------------------------
 struct LdsLayout {
     size_t fit, q, col, rowp, vlist, sv, wave0, wave_bytes, total;
-    size_t w_label, w_queue, w_segN, w_segP, w_inC, w_nflag, w_rbits, w_rpre, w_claim, w_bslot;
+    size_t w_label, w_nodes, w_equeue, w_cl, w_nflag, w_rbits, w_rpre, w_rng;
 };
 
-__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds)
+// esize: bytes of one entry of the examined-edge queue (2 while the frame has < 65536 directed edges)
+__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, int esize)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsLayout L;
@@ -172,16 +170,14 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     L.wave0 = o;
     const size_t NW = (size_t)(S + 31) / 32;
     size_t w = 0;
-    L.w_segP = w; w += A((size_t)S * 8);
     L.w_label = w; w += A((size_t)S * 2);
-    L.w_queue = w; w += A((size_t)S * 8);
-    L.w_segN = w; w += A((size_t)S * 2);
-    L.w_inC = w; w += A((size_t)S);
+    L.w_nodes = w; w += A((size_t)S * 2);
+    L.w_equeue = w; w += A((size_t)E2 * (size_t)esize + 128);
+    L.w_cl = w; w += A((size_t)S * 4);
     L.w_nflag = w; w += A((size_t)S);
     L.w_rbits = w; w += A(NW * 4);
     L.w_rpre = w; w += A(NW * 4);
-    L.w_claim = w; w += A((size_t)S * 4);
-    L.w_bslot = w; w += 256;
+    L.w_rng = w; w += 4 * 64 * 8;
     L.wave_bytes = w;
     L.total = o + w * (size_t)wpb;
     return L;
@@ -201,9 +197,12 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
         }                                                              \
     } while (0)
 
-template <int WPB, bool TAB_LDS, bool PROF>
+constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
+
+template <int WPB, bool TAB_LDS, bool E32, bool PROF>
 __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
 {
+    using ET = typename std::conditional<E32, uint32_t, uint16_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6;
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     const int S = a.S[frame];
     const int E2 = (int)a.E2[frame];
     const int NW = (S + 31) / 32;
-    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS);
+    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, (int)sizeof(ET));
 
     const double* g_fit = a.fit + (size_t)frame * a.s_max * kFitStride;
     const double* g_q = a.q + (size_t)frame * a.e2_max;
@@ -247,10 +246,16 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             if (ok) vlist[cnt + mbcnt(m)] = (uint16_t)i;
             cnt += __popcll((unsigned long long)m);
         }
+        // largest degree of the frame (bounds the per-node append loop of the growth)
+        uint32_t md = 0;
+        for (int i = lane; i < S; i += kWave) md = max(md, g_rowp[i + 1] - g_rowp[i]);
+        md = wave_scan_max_u32(md);
         if (lane == 0) *s_Sv = cnt;
+        if (lane == 63) s_Sv[1] = (int)md;
     }
     __syncthreads();
     const int Sv = *s_Sv;
+    const uint32_t maxdeg = (uint32_t)s_Sv[1];
     const int chain = chain0 + wave;
     if (chain >= a.n_chains || Sv == 0) return;
 
@@ -269,26 +274,21 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     // ---- wave-private state ----
     unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
-    double* segP = reinterpret_cast<double*>(wbase + L.w_segP);
     uint16_t* label = reinterpret_cast<uint16_t*>(wbase + L.w_label);
-    uint2* queue = reinterpret_cast<uint2*>(wbase + L.w_queue);   // .x = node | degree << 16, .y = first CSR entry
-    uint16_t* segN = reinterpret_cast<uint16_t*>(wbase + L.w_segN);
-    uint8_t* inC = wbase + L.w_inC;                                // 1 = in the component
-    uint8_t* nflag = wbase + L.w_nflag;                            // by label: 1 = neighbouring segment
+    uint16_t* nodes = reinterpret_cast<uint16_t*>(wbase + L.w_nodes);    // the component, FIFO order
+    ET* equeue = reinterpret_cast<ET*>(wbase + L.w_equeue);              // CSR entries in the order they are examined
+    uint32_t* cl = reinterpret_cast<uint32_t*>(wbase + L.w_cl);          // kFree, or in the component
+    uint8_t* nflag = wbase + L.w_nflag;                                   // by label: 1 = neighbouring segment
     uint32_t* nflagw = reinterpret_cast<uint32_t*>(wbase + L.w_nflag);
-    const int NWB = (int)(((size_t)S + 15) & ~(size_t)15) / 4;     // words of the flag arrays (zero padded)
+    const int NWB = (int)(((size_t)S + 15) & ~(size_t)15) / 4;            // words of the flag array (zero padded)
     uint32_t* rbits = reinterpret_cast<uint32_t*>(wbase + L.w_rbits);
     uint32_t* rpre = reinterpret_cast<uint32_t*>(wbase + L.w_rpre);
-    uint32_t* claim = reinterpret_cast<uint32_t*>(wbase + L.w_claim);   // lowest lane that joined a node in the current batch
-    uint32_t* bslot = reinterpret_cast<uint32_t*>(wbase + L.w_bslot);   // batch slot -> node of the batch
 
     uint16_t* g_label = a.label + (size_t)chain * a.s_max;
-    double* g_segP = a.segP + (size_t)chain * a.s_max;
+    // per-segment cache, row = the segment's name: 10 exact sums, sum of ssr, probabilityL, member count
     double* g_segC = a.segC + (size_t)chain * a.s_max * kSegCacheStride;
-    uint16_t* g_segN = a.segN + (size_t)chain * a.s_max;
-    for (int i = lane; i < S; i += kWave) { label[i] = g_label[i]; segP[i] = g_segP[i]; segN[i] = g_segN[i]; }
-    for (int w = lane; w < NWB; w += kWave) { reinterpret_cast<uint32_t*>(inC)[w] = 0u; nflagw[w] = 0u; }
-    for (int i = lane; i < S; i += kWave) claim[i] = 0xFFFFFFFFu;
+    for (int i = lane; i < S; i += kWave) { label[i] = g_label[i]; cl[i] = kFree; }
+    for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
 
     double energy = a.energy[chain], best_energy = a.best_energy[chain];
     uint64_t state_hash = a.state_hash[chain], trace_hash = a.trace_hash[chain];
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     Rng g;
     g.k0 = a.seed; g.k1 = a.chain_offset + (uint32_t)chain;
+    g.buf = reinterpret_cast<double*>(wbase + L.w_rng);
 
     unsigned long long* marg = a.marg + (size_t)frame * a.s_max * a.lmax;
     unsigned long long* vh = a.visit_hash + (size_t)chain * a.hcap;
@@ -370,96 +371,73 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
         uint8_t tb = 0xFF;
         if (status == 0) {
             g.step_lo = (uint32_t)t; g.step_hi = (uint32_t)(t >> 32);
-            rng_gen(g, 0, lane);
+            const u32x4 raw0 = rng_gen(g, 0, lane);
             // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161); the step's other
             // scalar draws are taken out of the batch now, before the growth moves on to later positions
-            const uint32_t start = vlist[(uint32_t)__builtin_amdgcn_readlane((int)g.w0, 0) % (uint32_t)Sv];
-            const double u1 = readlane_f64(g.r0, 2);
-            const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)g.w0, 3);
-            const double r_mh = readlane_f64(g.r0, 4);
+            const uint32_t start = vlist[(uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 0) % (uint32_t)Sv];
+            const double u1 = g.buf[2];
+            const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 3);
+            const double r_mh = g.buf[4];
             const uint32_t orig = label[start];
+            // the old segment's cache row (sums, probabilityL, size): in flight during the growth
+            double Co[kSegCacheUsed];
+#pragma unroll
+            for (int k = 0; k < kSegCacheUsed; ++k) Co[k] = g_segC[(size_t)orig * kSegCacheStride + k];
             MC_PHASE(0);
 
-            // ---- createComponent BFS (Segmentation.cpp:74-120), batched ----
-            // The reference pops one node at a time and tries its neighbours in order.  Every trial has its
-            // own counter-addressed uniform (see Rng), so the 64 lanes take the next 64 CSR entries of the
-            // nodes at the head of the FIFO (several nodes at once; the FIFO order of entries is the
-            // sequential order) and try them together.  A node reached through two open edges of one batch
-            // is taken by the lower lane, which is the entry the sequential loop would have reached first,
-            // so the component and the FIFO order are exactly the sequential ones.  A node whose entries
-            // cross the 64th slot resumes at `skip` in the next batch.
-            if (lane == 0) {
-                const uint32_t rs0 = rowp[start];
-                queue[0] = make_uint2(start | ((rowp[start + 1] - rs0) << 16), rs0);
-                inC[start] = 1;
+            // ---- createComponent BFS (Segmentation.cpp:74-120), 64 edges per pass ----
+            // The reference pops one node at a time and tries its neighbours in order.  Here a node that joins
+            // the component appends its CSR entries to `equeue`, so that queue holds the directed edges in
+            // exactly the order the sequential loop examines them, and its index is the position of the edge's
+            // uniform (see Rng).  A pass takes the next 64 entries, whichever nodes they belong to.  A node
+            // reached through two open edges of one pass is taken by the lower lane, which is the entry the
+            // sequential loop reaches first, so the component and the FIFO order are exactly the sequential ones.
+            uint32_t qn = 1, et, head = 0;
+            const uint32_t dump = (uint32_t)e2_lds + ((uint32_t)lane & 31u);
+            {
+                const uint32_t rs0 = rowp[start], d0 = rowp[start + 1] - rs0;
+                for (uint32_t tt = (uint32_t)lane; tt < d0; tt += kWave) equeue[tt] = (ET)(rs0 + tt);
+                if (lane == 0) { nodes[0] = (uint16_t)start; cl[start] = 0u; }
+                et = d0;
+                wave_fence();
             }
-            uint32_t qn = 1, head = 0, skip = 0, npos = kTrialPos0;
-            while (head < qn) {
-                const uint32_t K = min(qn - head, (uint32_t)kWave);
-                uint2 ent = make_uint2(0u, 0u);
-                if ((uint32_t)lane < K) ent = queue[head + (uint32_t)lane];
-                uint32_t deg = ent.x >> 16, rs = ent.y;
-                if (lane == 0) { deg -= skip; rs += skip; }
-                const uint32_t incl = wave_scan_add_u32(deg);
-                const uint32_t excl = incl - deg;
-                // nodes that start inside the 64 slots; the last one may be cut
-                const bool inb = (uint32_t)lane < K && excl < (uint32_t)kWave;
-                const uint32_t M = min((uint32_t)__builtin_amdgcn_readlane((int)incl, uni((int)K - 1)), (uint32_t)kWave);
-                // slot l belongs to the batch node with the largest excl <= l: mark the first slot of every node
-                // (nodes have at least one entry, so excl grows with the node index), max-scan, then pull that
-                // node's row start and first slot
-                // (lanes talk through LDS here: without the fences the compiler forwards a lane's own store
-                // to its load, as the memory model lets it for unsynchronised accesses)
-                bslot[lane] = 0u;
-                wave_fence();
-                if (inb && deg > 0u) bslot[excl] = (uint32_t)lane + 1u;
-                wave_fence();
-                const uint32_t tn = wave_scan_max_u32(bslot[lane]);
+            while (head < et) {
+                const uint32_t M = min(et - head, (uint32_t)kWave);
                 const bool act = (uint32_t)lane < M;
-                const int src = (int)((tn ? tn - 1u : 0u) * 4u);
-                const uint32_t rs_n = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rs);
-                const uint32_t ex_n = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)excl);
-                const uint32_t e = act ? (rs_n + ((uint32_t)lane - ex_n)) : 0u;
-                const uint32_t j = act ? colAt(e) : 0u;
+                const uint32_t e = act ? (uint32_t)equeue[head + (uint32_t)lane] : 0u;
+                const double r = rng_trial(g, kTrialPos0 + head, M, lane);
+                const uint32_t j = colAt(e);
                 const double qe = act ? qv[e] : -1.0;
-                const bool live = act && !(qe < 0.0);
-                const bool inc = inC[j] != 0;
+                const uint32_t cj = cl[j];
                 const uint32_t lj = label[j];
                 const uint32_t rj = rowp[j], dj = rowp[j + 1] - rj;
-                const bool elig = live && !inc && lj == orig;
-                const bool oth = live && !inc && lj != orig;
-                if (oth) nflag[lj] = 1;
-                const uint64_t em = __ballot(elig);
-                if (em) {
-                    const double r = rng_trial(g, npos, elig, lane);
-                    const bool join = elig && (r < qe);  // strict (Segmentation.cpp:110)
-                    if (__ballot(join)) {
-                        // several lanes may hold an open edge to the same node: the first in FIFO order takes it
-                        if (join) atomicMin(&claim[j], (uint32_t)lane);
-                        wave_fence();
-                        const bool win = join && claim[j] == (uint32_t)lane;
-                        wave_fence();
-                        if (join) claim[j] = 0xFFFFFFFFu;
-                        const uint64_t jm = __ballot(win);
-                        if (win) {
-                            inC[j] = 1;
-                            queue[qn + (uint32_t)mbcnt(jm)] = make_uint2(j | (dj << 16), rj);
-                        }
-                        wave_fence();
-                        qn += (uint32_t)__popcll((unsigned long long)jm);
-                    }
+                const bool live = !(qe < 0.0);
+                const bool fresh = live && cj == kFree;
+                const bool join = fresh && lj == orig && (r < qe);   // strict (Segmentation.cpp:110)
+                if (fresh && lj != orig) nflag[lj] = 1;
+                const uint64_t jm0 = __ballot(join);
+                if (jm0) {
+                    // several lanes may hold an open edge to the same node: the first in FIFO order takes it
+                    if (join) atomicMin(&cl[j], (uint32_t)lane);
+                    wave_fence();
+                    const bool win = join && cl[j] == (uint32_t)lane;
+                    const uint64_t wm = __ballot(win);
+                    const uint32_t dw = win ? dj : 0u;
+                    const uint32_t incl = wave_scan_add_u32(dw);
+                    const uint32_t base = et + incl - dw;
+                    if (win) nodes[qn + (uint32_t)mbcnt(wm)] = (uint16_t)j;
+                    for (uint32_t tt = 0; tt < maxdeg; ++tt)     // uniform bound, spare stores go to the pad
+                        equeue[tt < dw ? base + tt : dump] = (ET)(rj + tt);
+                    et += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    qn += (uint32_t)__popcll((unsigned long long)wm);
+                    wave_fence();
                 }
-                const uint32_t cmt = M;
-                // advance: nodes whose last slot is committed leave the FIFO; the next one resumes at `skip`
-                const uint32_t nfull = (uint32_t)__popcll((unsigned long long)__ballot(inb && incl <= cmt));
-                const uint32_t done = nfull ? (uint32_t)__builtin_amdgcn_readlane((int)incl, uni((int)nfull - 1)) : 0u;
-                skip = (nfull ? 0u : skip) + (cmt - done);
-                head += nfull;
-                npos += M;
+                head += M;
                 if constexpr (PROF) pacc[15] += 1;
             }
             const uint32_t csize = qn;
-            const bool same = csize == (uint32_t)segN[orig];  // Segmentation.cpp:19
+            const uint32_t segn_orig = (uint32_t)Co[kSegCacheN];
+            const bool same = csize == segn_orig;  // Segmentation.cpp:19
             MC_PHASE(1);
 
             // ---- selectSegment (Segmentation.cpp:10-57) ----
@@ -478,6 +456,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
             MC_PHASE(2);
             double targetL = 1.0, prop = ratio;  // Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic)
+            double logprop = 0.0;
             SegFit f1 = { 0.0, 0, 0, 0 }, f2 = { 0.0, 0, 0, 0 };
             double M2[kSumStride], M1[kSumStride], R2 = 0.0, R1 = 0.0;
 #pragma unroll
@@ -485,37 +464,38 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             int st = 0;
             const bool have1 = !same;  // sB1 = sA1 minus the component is not empty
             if (kase != 0) {
-                // cached sums of the two segments (Segment::combine / diff on sums instead of a refit from the
-                // member list, Graph.cpp:35-67): issued now, needed after the pass over the component
-                double Co[kSumStride + 1], Cn[kSumStride + 1];
+                // cached row of the target segment (Segment::combine / diff on sums instead of a refit from
+                // the member list, Graph.cpp:35-67): issued now, needed after the pass over the component
+                double Cn[kSegCacheUsed];
 #pragma unroll
-                for (int k = 0; k <= kSumStride; ++k) {
-                    Co[k] = have1 ? __hip_atomic_load(g_segC + (size_t)orig * kSegCacheStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                    Cn[k] = kase == 2 ? __hip_atomic_load(g_segC + (size_t)next * kSegCacheStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                }
+                for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = kase == 2 ? g_segC[(size_t)next * kSegCacheStride + k] : 0.0;
                 // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
-                // Graph.cpp:10-33) and the component's sums, wave order over the queue
-                double ps = 1.0, pm = 1.0, rp = 0.0;
+                // Graph.cpp:10-33), wave order over the examined-edge queue
+                double ps = 1.0, pm = 1.0;
+                for (uint32_t pos = (uint32_t)lane; pos < et; pos += kWave) {
+                    const uint32_t e = (uint32_t)equeue[pos];
+                    const double qe = qv[e];
+                    const uint32_t j = colAt(e);
+                    const uint32_t lj = label[j];
+                    const uint32_t cj = cl[j];
+                    const bool live = !(qe < 0.0);
+                    const double w = 1.0 - qe;
+                    // a factor of 1.0 is exact, so the untaken edges need no branch
+                    ps = ps * ((live && lj == orig && cj == kFree) ? w : 1.0);
+                    pm = pm * ((live && kase == 2 && lj == next && lj != orig) ? w : 1.0);
+                }
+                // the component's sums, wave order over the FIFO
+                double rp = 0.0;
                 double mc[kSumStride];
 #pragma unroll
                 for (int k = 0; k < kSumStride; ++k) mc[k] = 0.0;
                 int mn = 0x7FFFFFFF;
                 for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) {
-                    const uint2 ent = queue[h];
-                    const uint32_t i = ent.x & 0xFFFFu;
+                    const uint32_t i = nodes[h];
 #pragma unroll
                     for (int k = 0; k < kSumStride; ++k) mc[k] += recAt(i, k);
                     rp += recAt(i, kSumStride);
                     mn = min(mn, (int)i);
-                    const uint32_t rs = ent.y, re = ent.y + (ent.x >> 16);
-                    for (uint32_t e = rs; e < re; ++e) {
-                        const double qe = qv[e];
-                        if (qe < 0.0) continue;
-                        const uint32_t j = colAt(e);
-                        const uint32_t lj = label[j];
-                        if (lj == orig) { if (!inC[j]) ps = ps * (1.0 - qe); }
-                        else if (kase == 2 && lj == next) pm = pm * (1.0 - qe);
-                    }
                 }
                 MC_PHASE(3);
                 const double sep = wave_prod_f64(ps);
@@ -529,33 +509,36 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 for (int k = 0; k < kSumStride; ++k) { M2[k] = kase == 2 ? Cn[k] + mc[k] : mc[k]; M1[k] = Co[k] - mc[k]; }
                 R2 = kase == 2 ? Cn[kSumStride] + Rc : Rc;
                 R1 = Co[kSumStride] - Rc;
-                // the two evaluations run side by side: lanes 0..31 take sB2, lanes 32..63 sB1
-                {
-                    const bool hi = lane >= 32;
-                    double ms[kSumStride];
-#pragma unroll
-                    for (int k = 0; k < kSumStride; ++k) ms[k] = hi ? M1[k] : M2[k];
-                    if (hi && !have1) {   // no sB1: keep the arithmetic finite, the result is not used
-#pragma unroll
-                        for (int k = 0; k < kSumStride; ++k) ms[k] = M2[k];
-                    }
-                    Vec3 th; double err; int inf = 0;
-                    const double p = segment_from_sums(ms, hi ? R1 : R2, var, log_var, th, err, &inf);
-                    f2.probL = readlane_f64(p, 0);
-                    f1.probL = have1 ? readlane_f64(p, 32) : 0.0;
-                    const uint64_t im = __ballot(inf != 0);
-                    f2.inf_flag = (int)(im & 1ull);
-                    f1.inf_flag = have1 ? (int)((im >> 32) & 1ull) : 0;
-                }
-                f2.n = (int)csize + (kase == 2 ? (int)segN[next] : 0);
-                f2.minid = (kase == 2 && (int)next < minC) ? (int)next : minC;
-                f1.n = have1 ? (int)segN[orig] - (int)csize : 0;
-                MC_PHASE(5);
                 if (kase == 1) prop = ratio * (1.0 / sep);              // Problem.cpp:188
                 else prop = ratio * (mrg / sep);                        // Problem.cpp:206
+                // the two evaluations run side by side: lanes 0..31 take sB2, lanes 32..63 sB1; the three
+                // pivot logarithms of each and log(proposal ratio) are taken by different lane groups
+                {
+                    const bool hi = lane >= 32 && have1;   // without sB1 both halves evaluate sB2
+                    Sym3 A = { hi ? M1[0] : M2[0], hi ? M1[1] : M2[1], hi ? M1[2] : M2[2],
+                               hi ? M1[3] : M2[3], hi ? M1[4] : M2[4], hi ? M1[5] : M2[5] };
+                    Vec3 rr = { hi ? M1[6] : M2[6], hi ? M1[7] : M2[7], hi ? M1[8] : M2[8] }, th, d;
+                    const double quad = ldl3(A, rr, th, d);
+                    const double err = (((hi ? M1[9] : M2[9]) - quad) - (hi ? R1 : R2)) / (2.0 * var);
+                    const int gg = (lane >> 3) & 3;
+                    const double lx = det_log(gg == 0 ? d.x : (gg == 1 ? d.y : (gg == 2 ? d.z : prop)));
+                    logprop = readlane_f64(lx, 24);
+                    const double logdet2 = ((readlane_f64(lx, 0) + readlane_f64(lx, 8)) + readlane_f64(lx, 16)) - 3.0 * log_var;
+                    const double logdet1 = ((readlane_f64(lx, 32) + readlane_f64(lx, 40)) + readlane_f64(lx, 48)) - 3.0 * log_var;
+                    double p2 = -readlane_f64(err, 0) + 0.5 * (3.0 * kLog2Pi - logdet2);
+                    double p1 = -readlane_f64(err, 32) + 0.5 * (3.0 * kLog2Pi - logdet1);
+                    if (p2 != p2) p2 = 0.75;                 // Graph.cpp:134
+                    if (p1 != p1) p1 = 0.75;
+                    f2.probL = p2; f2.inf_flag = (p2 - p2 != 0.0) ? 1 : 0;   // Graph.cpp:137
+                    f1.probL = have1 ? p1 : 0.0; f1.inf_flag = (have1 && p1 - p1 != 0.0) ? 1 : 0;
+                }
+                f2.n = (int)csize + (kase == 2 ? (int)Cn[kSegCacheN] : 0);
+                f2.minid = (kase == 2 && (int)next < minC) ? (int)next : minC;
+                f1.n = have1 ? (int)segn_orig - (int)csize : 0;
+                MC_PHASE(5);
                 // jumpProbability (Problem.cpp:475-487)
-                const double sB2_sA1 = f2.probL - segP[orig];
-                const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? segP[next] : 0.0);
+                const double sB2_sA1 = f2.probL - Co[kSegCacheP];
+                const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? Cn[kSegCacheP] : 0.0);
                 targetL = sB2_sA1 + sB1_sA2;
                 if (f1.inf_flag || f2.inf_flag) st = -5;
                 if (targetL != targetL || prop != prop) st = -4;        // Problem.cpp:216-217
@@ -564,7 +547,8 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
             MC_PHASE(7);
             // ---- FastMetropolisHastings::iterate (MCMC.h:218-227) ----
-            const double aL = targetL + det_log(prop);
+            if (kase == 0) logprop = det_log(prop);
+            const double aL = targetL + logprop;
             const double acc = det_exp(aL);
             const double r = r_mh;  // always drawn
             bool accept = true;
@@ -579,10 +563,10 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 // jump (Problem.cpp:32-74) with smallest-member naming
                 const uint32_t L2 = (uint32_t)f2.minid;
                 uint32_t L1 = orig;
-                if (have1 && inC[orig]) {   // the old name moves with the component: smallest id left behind
+                if (have1 && cl[orig] != kFree) {   // the old name moves with the component: smallest id left behind
                     int m1 = 0x7FFFFFFF;
                     for (int i = lane; i < S; i += kWave)
-                        if (label[i] == orig && !inC[i]) m1 = min(m1, i);
+                        if (label[i] == orig && cl[i] == kFree) m1 = min(m1, i);
                     L1 = (uint32_t)wave_min_i32(m1);
                 }
                 uint64_t dh = 0;
@@ -590,7 +574,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     const uint32_t li = label[i];
                     if (li == kNoLabel) continue;
                     uint32_t nl = li;
-                    if (inC[i] || (kase == 2 && li == next)) nl = L2;
+                    if (cl[i] != kFree || (kase == 2 && li == next)) nl = L2;
                     else if (have1 && li == orig) nl = L1;
                     if (nl != li) {
                         dh += mix64(((uint64_t)i << 32) | nl) - mix64(((uint64_t)i << 32) | li);
@@ -598,20 +582,18 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     }
                 }
                 state_hash += wave_sum_u64(dh);
-                if (lane == 0) {
-                    segP[L2] = f2.probL; segN[L2] = (uint16_t)f2.n;
-                    if (have1) { segP[L1] = f1.probL; segN[L1] = (uint16_t)f1.n; }
-                }
-                // the new segments' sums go to the cache; the stores are complete (in L2) before any later
-                // step of this wave reads them back with an L2 (agent scope) load
-                if (lane <= kSumStride) {
-                    double v2 = R2, v1 = R1;
+                // the new segments' rows go to the cache; the stores are complete before any later step of
+                // this wave reads them back (same CU, same L1: workgroup scope)
+                if (lane < kSegCacheUsed) {
+                    double v2 = (double)f2.n, v1 = (double)f1.n;
 #pragma unroll
                     for (int k = 0; k < kSumStride; ++k) if (lane == k) { v2 = M2[k]; v1 = M1[k]; }
+                    if (lane == kSumStride) { v2 = R2; v1 = R1; }
+                    if (lane == kSegCacheP) { v2 = f2.probL; v1 = f1.probL; }
                     g_segC[(size_t)L2 * kSegCacheStride + lane] = v2;
                     if (have1) g_segC[(size_t)L1 * kSegCacheStride + lane] = v1;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 energy += targetL;
                 if (energy > best_energy) {
                     best_energy = energy;
@@ -621,13 +603,14 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 newlab = L2;
             }
             MC_PHASE(10);
-            if constexpr (PROF) { pacc[12] += csize; pacc[13] += npos; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
+            if constexpr (PROF) { pacc[12] += csize; pacc[13] += et; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
             if (accept) n_accept++;
             if (kase == 0) n_case0++; else if (kase == 1) n_case1++; else n_case2++;
 
             // clear the step's scratch flags
-            for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) inC[queue[h].x & 0xFFFFu] = 0;
+            for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) cl[nodes[h]] = kFree;
             for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
+            wave_fence();
 
             tb = (uint8_t)((accept ? 1 : 0) | (kase << 1));
             const uint64_t wd = (uint64_t)tb | ((uint64_t)start << 8) | ((uint64_t)csize << 24) | ((uint64_t)newlab << 40);
@@ -644,7 +627,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     }
 
     // ---- write the chain back ----
-    for (int i = lane; i < S; i += kWave) { g_label[i] = label[i]; g_segP[i] = segP[i]; g_segN[i] = segN[i]; }
+    for (int i = lane; i < S; i += kWave) g_label[i] = label[i];
     if (lane == 0) {
         a.energy[chain] = energy; a.best_energy[chain] = best_energy;
         a.state_hash[chain] = state_hash; a.trace_hash[chain] = trace_hash;
@@ -695,22 +678,20 @@ __global__ __launch_bounds__(64) void chain_init_kernel(ChainArgs a)
     uint16_t* lab = a.label + (size_t)chain * a.s_max;
     uint16_t* bl = a.best_label + (size_t)chain * a.s_max;
     uint16_t* tl = a.top_label + (size_t)chain * a.s_max;
-    double* segP = a.segP + (size_t)chain * a.s_max;
-    uint16_t* segN = a.segN + (size_t)chain * a.s_max;
     uint64_t h = 0;
     for (int i = lane; i < a.s_max; i += kWave) {
         const bool ok = i < S && valid[i];
         const uint16_t l = ok ? root : kNoLabel;
         lab[i] = l; bl[i] = l; tl[i] = l;
-        segP[i] = (ok && i == (int)root) ? p : 0.0;
-        segN[i] = (ok && i == (int)root) ? (uint16_t)n : (uint16_t)0;
         if (ok) h += mix64(((uint64_t)i << 32) | l);
     }
     h = wave_sum_u64(h);
-    if (n > 0 && lane <= kSumStride) {
-        double v = R;
+    if (n > 0 && lane < kSegCacheUsed) {
+        double v = (double)n;
 #pragma unroll
         for (int k = 0; k < kSumStride; ++k) if (lane == k) v = s[k];
+        if (lane == kSumStride) v = R;
+        if (lane == kSegCacheP) v = p;
         a.segC[((size_t)chain * a.s_max + root) * kSegCacheStride + lane] = v;
     }
     for (int i = lane; i < a.hcap; i += kWave) {
@@ -737,10 +718,10 @@ __global__ __launch_bounds__(64) void chain_energy_kernel(ChainArgs a, double* o
     const int frame = chain / a.chains_per_frame;
     const int S = a.S[frame];
     const uint16_t* lab = a.label + (size_t)chain * a.s_max;
-    const double* segP = a.segP + (size_t)chain * a.s_max;
+    const double* segC = a.segC + (size_t)chain * a.s_max * kSegCacheStride;
     double part = 0.0;
     for (int i = lane; i < S; i += kWave)
-        if (lab[i] == (uint16_t)i) part += segP[i];
+        if (lab[i] == (uint16_t)i) part += segC[(size_t)i * kSegCacheStride + kSegCacheP];
     const double e = wave_sum_f64(part);
     if (lane == 0) out[chain] = e;
 }
@@ -790,44 +771,49 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int WPB, bool TAB, bool PROF = false>
+template <int WPB, bool TAB, bool E32, bool PROF = false>
 static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
 {
-    if constexpr (!PROF && WPB == 4 && TAB) {
-        if (a.prof) return launch_variant<4, true, true>(a, s_lds, e2_lds, bytes, st);
+    if constexpr (!PROF && WPB == 4 && TAB && !E32) {
+        if (a.prof) return launch_variant<4, true, false, true>(a, s_lds, e2_lds, bytes, st);
     }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, PROF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, E32, PROF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
-    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, E32, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
     return hipGetLastError();
+}
+
+template <bool TAB, bool E32>
+static hipError_t launch_wpb(const ChainArgs& a, int wpb, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
+{
+    if (wpb == 4) return launch_variant<4, TAB, E32>(a, s_lds, e2_lds, bytes, st);
+    if (wpb == 2) return launch_variant<2, TAB, E32>(a, s_lds, e2_lds, bytes, st);
+    return launch_variant<1, TAB, E32>(a, s_lds, e2_lds, bytes, st);
 }
 
 hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out)
 {
     const size_t cap = kLdsLimit - 64;
     const int wpbs[3] = { 4, 2, 1 };
+    const bool e32 = e2_used_max >= 65536;
     for (int tab = 1; tab >= 0; --tab) {
+        if (tab && s_used_max >= 65536) continue;  // LDS columns are u16
         for (int wi = 0; wi < 3; ++wi) {
             const int wpb = wpbs[wi];
             if (a.chains_per_frame % wpb) continue;
-            const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0);
+            const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0, e32 ? 4 : 2);
             if (L.total > cap) continue;
             if (variant_out) *variant_out = tab * 10 + wpb;
-            if (tab) {
-                if (wpb == 4) return launch_variant<4, true>(a, s_used_max, e2_used_max, L.total, st);
-                if (wpb == 2) return launch_variant<2, true>(a, s_used_max, e2_used_max, L.total, st);
-                return launch_variant<1, true>(a, s_used_max, e2_used_max, L.total, st);
-            } else {
-                if (wpb == 4) return launch_variant<4, false>(a, s_used_max, e2_used_max, L.total, st);
-                if (wpb == 2) return launch_variant<2, false>(a, s_used_max, e2_used_max, L.total, st);
-                return launch_variant<1, false>(a, s_used_max, e2_used_max, L.total, st);
-            }
+            if (tab) return e32 ? launch_wpb<true, true>(a, wpb, s_used_max, e2_used_max, L.total, st)
+                                : launch_wpb<true, false>(a, wpb, s_used_max, e2_used_max, L.total, st);
+            return e32 ? launch_wpb<false, true>(a, wpb, s_used_max, e2_used_max, L.total, st)
+                       : launch_wpb<false, false>(a, wpb, s_used_max, e2_used_max, L.total, st);
         }
     }
     return hipErrorInvalidValue;

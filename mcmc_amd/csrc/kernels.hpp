@@ -5,7 +5,8 @@
 
 namespace mc {
 
-constexpr int kSegCacheStride = 12;
+// per-chain segment cache row (f64): 10 exact sums, sum of ssr, probabilityL, member count, pad
+constexpr int kSegCacheStride = 16, kSegCacheUsed = 13, kSegCacheP = 11, kSegCacheN = 12;
 
 struct MomentArgs {
     const int16_t* disp;       // [F][H][W]
@@ -61,9 +62,7 @@ struct ChainArgs {
     unsigned long long step0, burn_in, iters;
     double var, new_seg_prob;
     uint16_t* label;           // [C][s_max] min-id labels
-    double* segP;              // [C][s_max]
-    double* segC;              // [C][s_max][kSegCacheStride] sums of the segment named by the row: 10 exact sums, sum of ssr, pad
-    uint16_t* segN;            // [C][s_max]
+    double* segC;              // [C][s_max][kSegCacheStride] cache row of the segment named by the row index
     double* energy; double* best_energy;
     uint16_t* best_label; uint16_t* top_label;
     unsigned long long* state_hash; unsigned long long* trace_hash;

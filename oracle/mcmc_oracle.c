@@ -715,19 +715,21 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
         prop = ratio; targetL = 1.0;
     } else {
         /* separation / merge products (Segmentation.cpp:127-146, Graph.cpp:10-33) and the
-         * component's sums, wave order over the BFS queue */
+         * wave order over the stream of examined entries, and the component's sums, wave order over
+         * the BFS queue */
         double psep[ORC_NLANE], pmrg[ORC_NLANE], rpart[ORC_NLANE];
         double Mc[ORC_SUM_STRIDE] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
         int minC = S;
         for (int l = 0; l < ORC_NLANE; ++l) { psep[l] = 1.0; pmrg[l] = 1.0; rpart[l] = 0.0; }
+        uint32_t pos = 0;                        /* index in the stream of examined entries */
         for (uint32_t h = 0; h < qn; ++h) {
             uint32_t i = c->queue[h];
-            int l = (int)(h & (ORC_NLANE - 1));
             const double *f = c->fit + (size_t)i * ORC_FIT_STRIDE;
             rec_sums(f, Mc);
-            rpart[l] += f[13];
+            rpart[h & (ORC_NLANE - 1)] += f[13];
             if ((int)i < minC) minC = (int)i;
-            for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e) {
+            for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e, ++pos) {
+                int l = (int)(pos & (ORC_NLANE - 1));
                 double qe = c->q[e];
                 if (qe < 0.0) continue;
                 uint32_t j = c->col[e];
