@@ -21,8 +21,6 @@
 // Canonical order (the reference iterates std::set/std::map in heap-pointer
 // order, i.e. arbitrarily): superpixels by id; a segment is named by its
 // smallest member id.
-#include <type_traits>
-
 #include "device_math.hpp"
 #include "kernels.hpp"
 
@@ -46,7 +44,8 @@ struct Rng {
     double* buf;                  // LDS, [4][64]: the batch's draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
 };
 
-MC_D double to_unit(uint32_t x) { return (double)x / 4294967295.0; }
+// rand()/RAND_MAX as one multiplication by the f64 nearest to 1/(2^32 - 1): the largest word gives 1.0
+MC_D double to_unit(uint32_t x) { return (double)x * 2.3283064370807974e-10; }
 MC_D void wave_fence();
 
 // generates positions [256 batch, 256 batch + 256) into g.buf; returns the lane's raw words
@@ -152,11 +151,13 @@ struct SegFit {
 // ---------------------------------------------------------------------------
 struct LdsLayout {
     size_t fit, q, col, rowp, vlist, sv, wave0, wave_bytes, total;
-    size_t w_label, w_nodes, w_equeue, w_cl, w_nflag, w_rbits, w_rpre, w_rng;
+    size_t w_label, w_slots, w_cl, w_nflag, w_rbits, w_rpre, w_rng;
 };
 
-// esize: bytes of one entry of the examined-edge queue (2 while the frame has < 65536 directed edges)
-__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, int esize)
+// queue slots: one per node of the component, plus one per further 8 neighbours of a node
+__host__ __device__ inline size_t queue_slots(int S, int E2) { return (size_t)S + (size_t)E2 / 8 + 8; }
+
+__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsLayout L;
@@ -171,8 +172,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     const size_t NW = (size_t)(S + 31) / 32;
     size_t w = 0;
     L.w_label = w; w += A((size_t)S * 2);
-    L.w_nodes = w; w += A((size_t)S * 2);
-    L.w_equeue = w; w += A((size_t)E2 * (size_t)esize + 128);
+    L.w_slots = w; w += A(queue_slots(S, E2) * 8);
     L.w_cl = w; w += A((size_t)S * 4);
     L.w_nflag = w; w += A((size_t)S);
     L.w_rbits = w; w += A(NW * 4);
@@ -199,10 +199,9 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
 
 constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
 
-template <int WPB, bool TAB_LDS, bool E32, bool PROF>
+template <int WPB, bool TAB_LDS, bool PROF>
 __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
 {
-    using ET = typename std::conditional<E32, uint32_t, uint16_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6;
@@ -212,7 +211,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     const int S = a.S[frame];
     const int E2 = (int)a.E2[frame];
     const int NW = (S + 31) / 32;
-    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, (int)sizeof(ET));
+    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS);
 
     const double* g_fit = a.fit + (size_t)frame * a.s_max * kFitStride;
     const double* g_q = a.q + (size_t)frame * a.e2_max;
@@ -256,6 +255,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     __syncthreads();
     const int Sv = *s_Sv;
     const uint32_t maxdeg = (uint32_t)s_Sv[1];
+    const uint32_t maxparts = (maxdeg + 7u) >> 3;
     const int chain = chain0 + wave;
     if (chain >= a.n_chains || Sv == 0) return;
 
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     // ---- wave-private state ----
     unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
     uint16_t* label = reinterpret_cast<uint16_t*>(wbase + L.w_label);
-    uint16_t* nodes = reinterpret_cast<uint16_t*>(wbase + L.w_nodes);    // the component, FIFO order
-    ET* equeue = reinterpret_cast<ET*>(wbase + L.w_equeue);              // CSR entries in the order they are examined
+    // FIFO of the growth: .x = node | entries << 16 | part << 24, .y = first CSR entry of the part
+    uint2* slots = reinterpret_cast<uint2*>(wbase + L.w_slots);
     uint32_t* cl = reinterpret_cast<uint32_t*>(wbase + L.w_cl);          // kFree, or in the component
     uint8_t* nflag = wbase + L.w_nflag;                                   // by label: 1 = neighbouring segment
     uint32_t* nflagw = reinterpret_cast<uint32_t*>(wbase + L.w_nflag);
@@ -385,27 +385,31 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             for (int k = 0; k < kSegCacheUsed; ++k) Co[k] = g_segC[(size_t)orig * kSegCacheStride + k];
             MC_PHASE(0);
 
-            // ---- createComponent BFS (Segmentation.cpp:74-120), 64 edges per pass ----
-            // The reference pops one node at a time and tries its neighbours in order.  Here a node that joins
-            // the component appends its CSR entries to `equeue`, so that queue holds the directed edges in
-            // exactly the order the sequential loop examines them, and its index is the position of the edge's
-            // uniform (see Rng).  A pass takes the next 64 entries, whichever nodes they belong to.  A node
-            // reached through two open edges of one pass is taken by the lower lane, which is the entry the
-            // sequential loop reaches first, so the component and the FIFO order are exactly the sequential ones.
-            uint32_t qn = 1, et, head = 0;
-            const uint32_t dump = (uint32_t)e2_lds + ((uint32_t)lane & 31u);
+            // ---- createComponent BFS (Segmentation.cpp:74-120), 8 queue slots x 8 neighbours per pass ----
+            // The reference pops one node at a time and tries its neighbours in order.  Here the FIFO is made of
+            // slots of at most 8 neighbours (a node with more takes consecutive slots), a pass takes the next 8
+            // slots, lane = 8 * slot + neighbour, and the trial of neighbour s of slot k owns the uniform at
+            // position 8 + 8 k + s (see Rng) whether or not it is needed.  A node reached through two open edges
+            // of one pass is taken by the lower lane, which is the edge the sequential loop reaches first, so the
+            // component and the FIFO order are exactly the sequential ones.
+            uint32_t qn = 1, qt, head = 0;
             {
                 const uint32_t rs0 = rowp[start], d0 = rowp[start + 1] - rs0;
-                for (uint32_t tt = (uint32_t)lane; tt < d0; tt += kWave) equeue[tt] = (ET)(rs0 + tt);
-                if (lane == 0) { nodes[0] = (uint16_t)start; cl[start] = 0u; }
-                et = d0;
+                const uint32_t parts0 = d0 <= 8u ? 1u : (d0 + 7u) >> 3;
+                for (uint32_t pp = (uint32_t)lane; pp < parts0; pp += kWave)
+                    slots[pp] = make_uint2(start | (min(8u, d0 - 8u * pp) << 16) | (pp << 24), rs0 + 8u * pp);
+                if (lane == 0) cl[start] = 0u;
+                qt = parts0;
                 wave_fence();
             }
-            while (head < et) {
-                const uint32_t M = min(et - head, (uint32_t)kWave);
-                const bool act = (uint32_t)lane < M;
-                const uint32_t e = act ? (uint32_t)equeue[head + (uint32_t)lane] : 0u;
-                const double r = rng_trial(g, kTrialPos0 + head, M, lane);
+            const uint32_t g8 = (uint32_t)lane >> 3, s8 = (uint32_t)lane & 7u;
+            while (head < qt) {
+                const uint32_t K = min(qt - head, 8u);
+                uint2 ent = make_uint2(0u, 0u);
+                if (g8 < K) ent = slots[head + g8];
+                const bool act = s8 < ((ent.x >> 16) & 0xFFu);
+                const uint32_t e = act ? ent.y + s8 : 0u;
+                const double r = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
                 const uint32_t j = colAt(e);
                 const double qe = act ? qv[e] : -1.0;
                 const uint32_t cj = cl[j];
@@ -422,17 +426,28 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     wave_fence();
                     const bool win = join && cl[j] == (uint32_t)lane;
                     const uint64_t wm = __ballot(win);
-                    const uint32_t dw = win ? dj : 0u;
-                    const uint32_t incl = wave_scan_add_u32(dw);
-                    const uint32_t base = et + incl - dw;
-                    if (win) nodes[qn + (uint32_t)mbcnt(wm)] = (uint16_t)j;
-                    for (uint32_t tt = 0; tt < maxdeg; ++tt)     // uniform bound, spare stores go to the pad
-                        equeue[tt < dw ? base + tt : dump] = (ET)(rj + tt);
-                    et += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        if (maxdeg <= 8u) {
+                        if (win) slots[qt + (uint32_t)mbcnt(wm)] = make_uint2(j | (dj << 16), rj);
+                        qt += (uint32_t)__popcll((unsigned long long)wm);
+                    } else if (maxdeg <= 16u) {
+                        const bool big = win && dj > 8u;
+                        const uint64_t bm = __ballot(big);
+                        const uint32_t base = qt + (uint32_t)mbcnt(wm) + (uint32_t)mbcnt(bm);
+                        if (win) slots[base] = make_uint2(j | (min(8u, dj) << 16), rj);
+                        if (big) slots[base + 1u] = make_uint2(j | ((dj - 8u) << 16) | (1u << 24), rj + 8u);
+                        qt += (uint32_t)__popcll((unsigned long long)wm) + (uint32_t)__popcll((unsigned long long)bm);
+                    } else {
+                        const uint32_t parts = win ? (dj <= 8u ? 1u : (dj + 7u) >> 3) : 0u;
+                        const uint32_t incl = wave_scan_add_u32(parts);
+                        const uint32_t base = qt + incl - parts;
+                        for (uint32_t pp = 0; pp < maxparts; ++pp)
+                            if (pp < parts) slots[base + pp] = make_uint2(j | (min(8u, dj - 8u * pp) << 16) | (pp << 24), rj + 8u * pp);
+                        qt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    }
                     qn += (uint32_t)__popcll((unsigned long long)wm);
                     wave_fence();
                 }
-                head += M;
+                head += K;
                 if constexpr (PROF) pacc[15] += 1;
             }
             const uint32_t csize = qn;
@@ -472,9 +487,12 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
                 // Graph.cpp:10-33), wave order over the examined-edge queue
                 double ps = 1.0, pm = 1.0;
-                for (uint32_t pos = (uint32_t)lane; pos < et; pos += kWave) {
-                    const uint32_t e = (uint32_t)equeue[pos];
-                    const double qe = qv[e];
+                for (uint32_t b8 = 0; b8 < qt; b8 += 8u) {
+                    uint2 ent = make_uint2(0u, 0u);
+                    if (b8 + g8 < qt) ent = slots[b8 + g8];
+                    const bool act = s8 < ((ent.x >> 16) & 0xFFu);
+                    const uint32_t e = act ? ent.y + s8 : 0u;
+                    const double qe = act ? qv[e] : -1.0;
                     const uint32_t j = colAt(e);
                     const uint32_t lj = label[j];
                     const uint32_t cj = cl[j];
@@ -484,14 +502,16 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     ps = ps * ((live && lj == orig && cj == kFree) ? w : 1.0);
                     pm = pm * ((live && kase == 2 && lj == next && lj != orig) ? w : 1.0);
                 }
-                // the component's sums, wave order over the FIFO
+                // the component's sums, wave order over the FIFO slots (a node counts at its first slot)
                 double rp = 0.0;
                 double mc[kSumStride];
 #pragma unroll
                 for (int k = 0; k < kSumStride; ++k) mc[k] = 0.0;
                 int mn = 0x7FFFFFFF;
-                for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) {
-                    const uint32_t i = nodes[h];
+                for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) {
+                    const uint32_t ex = slots[h].x;
+                    if ((ex >> 24) != 0u) continue;
+                    const uint32_t i = ex & 0xFFFFu;
 #pragma unroll
                     for (int k = 0; k < kSumStride; ++k) mc[k] += recAt(i, k);
                     rp += recAt(i, kSumStride);
@@ -603,12 +623,12 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 newlab = L2;
             }
             MC_PHASE(10);
-            if constexpr (PROF) { pacc[12] += csize; pacc[13] += et; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
+            if constexpr (PROF) { pacc[12] += csize; pacc[13] += 8ull * qt; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
             if (accept) n_accept++;
             if (kase == 0) n_case0++; else if (kase == 1) n_case1++; else n_case2++;
 
             // clear the step's scratch flags
-            for (uint32_t h = (uint32_t)lane; h < qn; h += kWave) cl[nodes[h]] = kFree;
+            for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) cl[slots[h].x & 0xFFFFu] = kFree;
             for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
             wave_fence();
 
@@ -771,49 +791,44 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int WPB, bool TAB, bool E32, bool PROF = false>
+template <int WPB, bool TAB, bool PROF = false>
 static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
 {
-    if constexpr (!PROF && WPB == 4 && TAB && !E32) {
-        if (a.prof) return launch_variant<4, true, false, true>(a, s_lds, e2_lds, bytes, st);
+    if constexpr (!PROF && WPB == 4 && TAB) {
+        if (a.prof) return launch_variant<4, true, true>(a, s_lds, e2_lds, bytes, st);
     }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, E32, PROF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, PROF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
-    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, E32, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
     return hipGetLastError();
-}
-
-template <bool TAB, bool E32>
-static hipError_t launch_wpb(const ChainArgs& a, int wpb, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
-{
-    if (wpb == 4) return launch_variant<4, TAB, E32>(a, s_lds, e2_lds, bytes, st);
-    if (wpb == 2) return launch_variant<2, TAB, E32>(a, s_lds, e2_lds, bytes, st);
-    return launch_variant<1, TAB, E32>(a, s_lds, e2_lds, bytes, st);
 }
 
 hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out)
 {
     const size_t cap = kLdsLimit - 64;
     const int wpbs[3] = { 4, 2, 1 };
-    const bool e32 = e2_used_max >= 65536;
     for (int tab = 1; tab >= 0; --tab) {
-        if (tab && s_used_max >= 65536) continue;  // LDS columns are u16
         for (int wi = 0; wi < 3; ++wi) {
             const int wpb = wpbs[wi];
             if (a.chains_per_frame % wpb) continue;
-            const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0, e32 ? 4 : 2);
+            const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0);
             if (L.total > cap) continue;
             if (variant_out) *variant_out = tab * 10 + wpb;
-            if (tab) return e32 ? launch_wpb<true, true>(a, wpb, s_used_max, e2_used_max, L.total, st)
-                                : launch_wpb<true, false>(a, wpb, s_used_max, e2_used_max, L.total, st);
-            return e32 ? launch_wpb<false, true>(a, wpb, s_used_max, e2_used_max, L.total, st)
-                       : launch_wpb<false, false>(a, wpb, s_used_max, e2_used_max, L.total, st);
+            if (tab) {
+                if (wpb == 4) return launch_variant<4, true>(a, s_used_max, e2_used_max, L.total, st);
+                if (wpb == 2) return launch_variant<2, true>(a, s_used_max, e2_used_max, L.total, st);
+                return launch_variant<1, true>(a, s_used_max, e2_used_max, L.total, st);
+            } else {
+                if (wpb == 4) return launch_variant<4, false>(a, s_used_max, e2_used_max, L.total, st);
+                if (wpb == 2) return launch_variant<2, false>(a, s_used_max, e2_used_max, L.total, st);
+                return launch_variant<1, false>(a, s_used_max, e2_used_max, L.total, st);
+            }
         }
     }
     return hipErrorInvalidValue;

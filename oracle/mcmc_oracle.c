@@ -82,15 +82,16 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
  *   p = 2  selectSegment's uniform                (Segmentation.cpp:23)
  *   p = 3  selectSegment's index                  (Segmentation.cpp:40)
  *   p = 4  the Metropolis-Hastings uniform        (MCMC.h:223)
- *   p = 8 + n  the Swendsen-Wang trial of the n-th CSR entry examined by
- *          createComponent (n counts every entry of every popped node in FIFO
- *          order, whether or not it needs a trial).
+ *   p = 8 + 8 k + s  the Swendsen-Wang trial of neighbour s of FIFO slot k of
+ *          createComponent: a popped node takes one slot per 8 neighbours (at
+ *          least one), slots are numbered in FIFO order, and a neighbour owns its
+ *          position whether or not it needs a trial.
  * The reference hands a trial whatever rand() returns next, which makes the draw a
- * trial gets depend on how many trials happened before it.  Numbering by examined
- * entry keeps the trials independent uniforms in sequential order (an entry is
- * examined at most once per step) but makes the position of a trial a prefix sum of
- * node degrees, so the GPU can try 64 entries of several FIFO nodes in one pass and
- * serve four passes from one Philox call.  The component, the FIFO order and every
+ * trial gets depend on how many trials happened before it.  Numbering by FIFO
+ * slot keeps the trials independent uniforms in sequential order (an entry is
+ * examined at most once per step) and makes the position of a trial a function of
+ * the node's place in the FIFO alone, so the GPU can try the neighbours of 8 FIFO
+ * slots in one pass and serve four passes from one Philox call.  The component, the FIFO order and every
  * later decision are unchanged functions of those uniforms.
  */
 #define ORC_TRIAL_POS0 8u
@@ -121,10 +122,11 @@ static uint32_t rng_u32_at(orc_rng *g, uint32_t p)
     return g->buf[lane][w];
 }
 
-/* rand()/RAND_MAX is inclusive of 1.0 (MCMC.h:223, Segmentation.cpp:23,109). */
+/* rand()/RAND_MAX is inclusive of 1.0 (MCMC.h:223, Segmentation.cpp:23,109): one
+ * multiplication by the f64 nearest to 1/(2^32 - 1); the largest word gives 1.0. */
 static double rng_unif_at(orc_rng *g, uint32_t p)
 {
-    return (double)rng_u32_at(g, p) / 4294967295.0;
+    return (double)rng_u32_at(g, p) * 2.3283064370807974e-10;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -667,12 +669,16 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
     const uint16_t orig = lab[start];
 
     /* createComponent BFS (Segmentation.cpp:74-120) */
-    uint32_t qn = 0, npos = ORC_TRIAL_POS0;
+    /* The FIFO is counted in slots of at most 8 neighbours (a node with more takes consecutive
+     * slots); the trial of neighbour s of slot k owns the uniform at position 8 + 8 k + s. */
+    uint32_t qn = 0, slot = 0;
     c->queue[qn++] = start; c->inC[start] = 1;
     for (uint32_t head = 0; head < qn; ++head) {
         uint32_t i = c->queue[head];
-        for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e) {
-            const uint32_t p = npos++;            /* position of this entry in the examined stream */
+        const uint32_t rs = c->row_ptr[i], deg = c->row_ptr[i + 1] - rs;
+        for (uint32_t e = rs; e < rs + deg; ++e) {
+            const uint32_t kk = e - rs;
+            const uint32_t p = ORC_TRIAL_POS0 + 8u * (slot + (kk >> 3)) + (kk & 7u);
             double qe = c->q[e];
             if (qe < 0.0) continue;               /* not an edge in the reference graph */
             uint32_t j = c->col[e];
@@ -681,6 +687,7 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
             double r = rng_unif_at(&g, p);        /* :109 */
             if (r < qe) { c->inC[j] = 1; c->queue[qn++] = j; } /* :110-117, strict */
         }
+        slot += deg <= 8u ? 1u : (deg + 7u) >> 3;
     }
     const uint32_t csize = qn;
     const int same = (csize == segN[orig]);      /* Segmentation.cpp:19 */
@@ -721,21 +728,24 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
         double Mc[ORC_SUM_STRIDE] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
         int minC = S;
         for (int l = 0; l < ORC_NLANE; ++l) { psep[l] = 1.0; pmrg[l] = 1.0; rpart[l] = 0.0; }
-        uint32_t pos = 0;                        /* index in the stream of examined entries */
+        uint32_t slot = 0;                       /* FIFO slot of the node's first 8 neighbours */
         for (uint32_t h = 0; h < qn; ++h) {
             uint32_t i = c->queue[h];
             const double *f = c->fit + (size_t)i * ORC_FIT_STRIDE;
+            const uint32_t rs = c->row_ptr[i], deg = c->row_ptr[i + 1] - rs;
             rec_sums(f, Mc);
-            rpart[h & (ORC_NLANE - 1)] += f[13];
+            rpart[slot & (ORC_NLANE - 1)] += f[13];
             if ((int)i < minC) minC = (int)i;
-            for (uint32_t e = c->row_ptr[i]; e < c->row_ptr[i + 1]; ++e, ++pos) {
-                int l = (int)(pos & (ORC_NLANE - 1));
+            for (uint32_t e = rs; e < rs + deg; ++e) {
+                const uint32_t kk = e - rs;
+                int l = (int)((8u * (slot + (kk >> 3)) + (kk & 7u)) & (ORC_NLANE - 1));
                 double qe = c->q[e];
                 if (qe < 0.0) continue;
                 uint32_t j = c->col[e];
                 if (lab[j] == orig) { if (!c->inC[j]) psep[l] = psep[l] * (1.0 - qe); }
                 else if (kase == 2 && lab[j] == next) pmrg[l] = pmrg[l] * (1.0 - qe);
             }
+            slot += deg <= 8u ? 1u : (deg + 7u) >> 3;
         }
         double sep = wave_prod(psep);
         const double Rc = wave_sum(rpart);
