@@ -487,20 +487,36 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
                 // Graph.cpp:10-33), wave order over the examined-edge queue
                 double ps = 1.0, pm = 1.0;
-                for (uint32_t b8 = 0; b8 < qt; b8 += 8u) {
-                    uint2 ent = make_uint2(0u, 0u);
-                    if (b8 + g8 < qt) ent = slots[b8 + g8];
-                    const bool act = s8 < ((ent.x >> 16) & 0xFFu);
-                    const uint32_t e = act ? ent.y + s8 : 0u;
-                    const double qe = act ? qv[e] : -1.0;
-                    const uint32_t j = colAt(e);
-                    const uint32_t lj = label[j];
-                    const uint32_t cj = cl[j];
-                    const bool live = !(qe < 0.0);
-                    const double w = 1.0 - qe;
-                    // a factor of 1.0 is exact, so the untaken edges need no branch
-                    ps = ps * ((live && lj == orig && cj == kFree) ? w : 1.0);
-                    pm = pm * ((live && kase == 2 && lj == next && lj != orig) ? w : 1.0);
+                // four blocks of 8 slots per trip: their LDS round trips overlap, the factors are applied in
+                // block order
+                for (uint32_t b8 = 0; b8 < qt; b8 += 32u) {
+                    uint2 ent[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t sl = b8 + 8u * (uint32_t)u + g8;
+                        ent[u] = slots[sl < qt ? sl : 0u];
+                        if (sl >= qt) ent[u].x = 0u;
+                    }
+                    double qe[4]; uint32_t jj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool act = s8 < ((ent[u].x >> 16) & 0xFFu);
+                        const uint32_t e = act ? ent[u].y + s8 : 0u;
+                        const double qx = qv[e];
+                        qe[u] = act ? qx : -1.0;
+                        jj[u] = colAt(e);
+                    }
+                    uint32_t lj[4], cj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { lj[u] = label[jj[u]]; cj[u] = cl[jj[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool live = !(qe[u] < 0.0);
+                        const double w = 1.0 - qe[u];
+                        // a factor of 1.0 is exact, so the untaken edges need no branch
+                        ps = ps * ((live && lj[u] == orig && cj[u] == kFree) ? w : 1.0);
+                        pm = pm * ((live && kase == 2 && lj[u] == next && lj[u] != orig) ? w : 1.0);
+                    }
                 }
                 // the component's sums, wave order over the FIFO slots (a node counts at its first slot)
                 double rp = 0.0;
