@@ -33,6 +33,7 @@ extern "C" {
 #define MCMC_E_INF_ENERGY (-5)   /* "log probability is inf" Graph.cpp:137 */
 #define MCMC_E_TOO_LARGE (-6)    /* superpixel count beyond what the chain kernel's LDS state holds */
 #define MCMC_E_NOSUPERPIXELS (-7)/* frame has no superpixel that passes the A1 filter */
+#define MCMC_E_RANGE (-8)        /* "Weird channel value." OverSegmentation.cpp:382 */
 
 #define MCMC_NOLABEL 0xFFFFu     /* pixel / superpixel that belongs to no superpixel / segment */
 #define MCMC_MOMENT_STRIDE 10    /* N Su Sv Suu Suv Svv Sb Sub Svb Sbb (int64) */
@@ -155,6 +156,51 @@ int mcmc_chains_get_profile(mcmc_ctx *ctx, uint64_t *out16);
 int mcmc_selftest_math(mcmc_ctx *ctx, const double *x, const double *y, int n, double *out_log,
                        double *out_exp, double *out_div);
 int mcmc_selftest_philox(mcmc_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* ======================================================================== *
+ * Over-segmentation front end: the producer of the
+ * label map and superpixel graph above.  Replaces OverSegmentation::overSegment
+ * steps 1-4 (src/libraries/OverSegmentation.cpp:19-48); step 5 is
+ * mcmc_frames_edge_probs.
+ * ======================================================================== */
+typedef struct mcmc_overseg mcmc_overseg;
+
+/* OverSegmentationParameters (include/OverSegmentation.h:18-44), file order of
+ * output/overSegmentationParams.txt (IO.cpp:105-134). */
+typedef struct mcmc_overseg_params {
+    int window_size;          /* windowSize_: < 2 skips the filter */
+    double spatial_stdev;     /* spatialStdev_ */
+    double disparity_stdev;   /* disparityStdev_ */
+    int weight_threshold;     /* weightThreshold_ (size_t in the reference, the c of segment_graph) */
+    double color_factor, disparity_factor, distance_factor;
+} mcmc_overseg_params;
+
+void mcmc_overseg_default_params(mcmc_overseg_params *p);   /* 9 / 5.0 / 3.0 / 300 / 1 / 1 / 1 */
+int mcmc_overseg_create(int device, int width, int height, mcmc_overseg **out);
+int mcmc_overseg_destroy(mcmc_overseg *os);
+const char *mcmc_overseg_last_error(const mcmc_overseg *os);
+
+/* overSegment steps 1-4 (OverSegmentation.cpp:25-48): cross-bilateral filter of
+ * the colours by the disparities (:304-391), 4 edges per pixel weighted by
+ * colour, disparity and distance (:236-301), Felzenszwalb-Huttenlocher
+ * union-find over the sorted edges (segment-graph.h:47-111; on the host, as in
+ * the reference), createSuperPixels (:89-194: dense labels in ascending root
+ * pixel order = the std::map order, neighbours through LEFT / TOP / TOP-RIGHT
+ * contacts).  colors: H*W*3 bytes in cv::Vec3b order (B, G, R); disp: H*W shorts.
+ * Errors: MCMC_E_BADARG for non-positive deviations (the reference throws,
+ * :309-310), MCMC_E_RANGE for "Weird channel value." (:382), MCMC_E_TOO_LARGE
+ * when more than 65534 superpixels come out. */
+int mcmc_overseg_run(mcmc_overseg *os, const uint8_t *colors, const int16_t *disp,
+                     const mcmc_overseg_params *params, int *n_superpixels, uint32_t *n_directed_edges);
+/* Results of the last run.  The device buffers (int16 disparities, uint16 labels)
+ * can be handed to mcmc_frame_upload_device, the graph to mcmc_frame_set_graph. */
+int mcmc_overseg_get_smoothed(mcmc_overseg *os, uint8_t *out /* H*W*3 */);
+long long mcmc_overseg_get_edges(mcmc_overseg *os, int32_t *a, int32_t *b, float *w /* creation order, any may be NULL; returns the count */);
+int mcmc_overseg_get_roots(mcmc_overseg *os, int32_t *out /* H*W: universe::find(k) */);
+int mcmc_overseg_get_labels(mcmc_overseg *os, uint16_t *out /* H*W */);
+int mcmc_overseg_get_graph(mcmc_overseg *os, uint32_t *row_ptr /* S+1 */, uint32_t *col /* e2 */);
+int mcmc_overseg_device_buffers(mcmc_overseg *os, const void **d_disp, const void **d_label);
+int mcmc_overseg_last_ms(mcmc_overseg *os, float *filter_ms, float *edges_ms, float *union_find_ms, float *graph_ms);
 
 /* ======================================================================== *
  * Path B: multiview segmentation over an SPGraph (world graph of several

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcmc_amd.so")
-SOURCES = ["capi.hip", "capi_multiview.hip", "frame_kernels.hip", "chain_kernels.hip", "multiview_kernels.hip"]
+SOURCES = ["capi.hip", "capi_multiview.hip", "capi_overseg.hip", "frame_kernels.hip", "chain_kernels.hip", "multiview_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]

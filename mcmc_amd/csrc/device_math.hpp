@@ -111,6 +111,26 @@ MC_HD double det_exp(double x)
     return (p * s1) * s2;
 }
 
+// ---- det_sqrt: Newton iteration from IEEE + * / only, identical on CPU and GPU ----
+MC_HD double det_sqrt(double x)
+{
+    if (x != x) return x;
+    if (x < 0.0) return u2d(0x7FF8000000000000ull);
+    if (x == 0.0) return x;
+    uint64_t u = d2u(x);
+    if (u == 0x7FF0000000000000ull) return x;
+    int e = 0;
+    if ((u >> 52) == 0) { x = x * 18014398509481984.0 * 18014398509481984.0; u = d2u(x); e = -108; }
+    e += (int)(u >> 52) - 1023;
+    const int odd = e & 1;
+    e -= odd;
+    const double m = u2d((u & 0x000FFFFFFFFFFFFFull) | ((uint64_t)(1023 + odd) << 52));
+    double y = (m + 2.0) / 3.0;
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) y = 0.5 * (y + m / y);
+    return y * u2d((uint64_t)(e / 2 + 1023) << 52);
+}
+
 // ---- 3x3 SPD solve (LDL^T, no pivoting, fixed order) -----------------------
 // a = {a11 a12 a22 a13 a23 a33}; unknown order (a, b, c) for rows [u v 1].
 struct Sym3 { double a11, a12, a22, a13, a23, a33; };

@@ -28,25 +28,6 @@ constexpr uint32_t kPhiloxTagMv = 0x4D564D43u;  // "MVMC"
 constexpr int kMvWaves = 4;
 constexpr int kMvThreads = kMvWaves * 64;
 
-MC_HD double det_sqrt(double x)
-{
-    if (x != x) return x;
-    if (x < 0.0) return u2d(0x7FF8000000000000ull);
-    if (x == 0.0) return x;
-    uint64_t u = d2u(x);
-    if (u == 0x7FF0000000000000ull) return x;
-    int e = 0;
-    if ((u >> 52) == 0) { x = x * 18014398509481984.0 * 18014398509481984.0; u = d2u(x); e = -108; }
-    e += (int)(u >> 52) - 1023;
-    const int odd = e & 1;
-    e -= odd;
-    const double m = u2d((u & 0x000FFFFFFFFFFFFFull) | ((uint64_t)(1023 + odd) << 52));
-    double y = (m + 2.0) / 3.0;
-#pragma unroll 1
-    for (int i = 0; i < 6; ++i) y = 0.5 * (y + m / y);
-    return y * u2d((uint64_t)(e / 2 + 1023) << 52);
-}
-
 struct Sym33 { double a00, a01, a02, a11, a12, a22; };
 struct Mat33 { double m[3][3]; };
 

@@ -38,6 +38,13 @@ class Params(C.Structure):
 _lib = None
 
 
+class OversegParams(C.Structure):
+    """mcmc_overseg_params of include/mcmc_amd.h (OverSegmentationParameters)."""
+    _fields_ = [("window_size", C.c_int), ("spatial_stdev", C.c_double), ("disparity_stdev", C.c_double),
+                ("weight_threshold", C.c_int), ("color_factor", C.c_double), ("disparity_factor", C.c_double),
+                ("distance_factor", C.c_double)]
+
+
 def _ptr(a, dtype):
     if a is None:
         return None
@@ -105,6 +112,18 @@ def load():
         "mcmc_mv_chains_get_scalars": (i, [vp] + [vp] * 6),
         "mcmc_mv_chains_get_planes": (i, [vp, i, vp]),
         "mcmc_mv_last_run_ms": (dbl, [vp]),
+        "mcmc_overseg_default_params": (None, [C.POINTER(OversegParams)]),
+        "mcmc_overseg_create": (i, [i, i, i, C.POINTER(vp)]),
+        "mcmc_overseg_destroy": (i, [vp]),
+        "mcmc_overseg_last_error": (C.c_char_p, [vp]),
+        "mcmc_overseg_run": (i, [vp, vp, vp, C.POINTER(OversegParams), C.POINTER(i), C.POINTER(u32)]),
+        "mcmc_overseg_get_smoothed": (i, [vp, vp]),
+        "mcmc_overseg_get_edges": (C.c_longlong, [vp, vp, vp, vp]),
+        "mcmc_overseg_get_roots": (i, [vp, vp]),
+        "mcmc_overseg_get_labels": (i, [vp, vp]),
+        "mcmc_overseg_get_graph": (i, [vp, vp, vp]),
+        "mcmc_overseg_device_buffers": (i, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "mcmc_overseg_last_ms": (i, [vp] + [C.POINTER(C.c_float)] * 4),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -395,3 +414,88 @@ class Multiview:
 
     def last_run_ms(self):
         return float(self.L.mcmc_mv_last_run_ms(self.h))
+
+
+class OverSegmenter:
+    """Over-segmentation front end (mcmc_overseg_* of include/mcmc_amd.h): colours + disparities ->
+    label map, superpixel count and neighbour graph, ready for Context.frame_upload_device /
+    frame_set_graph.  Mirrors OverSegmentation::overSegment steps 1-4."""
+
+    def __init__(self, width=640, height=480, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        self.W, self.H = width, height
+        rc = self.L.mcmc_overseg_create(device, width, height, C.byref(self.h))
+        if rc != 0:
+            raise McmcError(rc, "mcmc_overseg_create failed (no GPU?)")
+        self.S = 0
+        self.e2 = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise McmcError(rc, self.L.mcmc_overseg_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.mcmc_overseg_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def default_params(self):
+        p = OversegParams()
+        self.L.mcmc_overseg_default_params(C.byref(p))
+        return p
+
+    def run(self, colors, disp, params=None):
+        """colors: (H, W, 3) uint8 in B, G, R order; disp: (H, W) int16.  Returns (S, e2)."""
+        p = params if params is not None else self.default_params()
+        colors = np.ascontiguousarray(colors, np.uint8); disp = np.ascontiguousarray(disp, np.int16)
+        assert colors.shape == (self.H, self.W, 3) and disp.shape == (self.H, self.W)
+        S = C.c_int(0); e2 = C.c_uint32(0)
+        self._ck(self.L.mcmc_overseg_run(self.h, _ptr(colors, np.uint8), _ptr(disp, np.int16), C.byref(p),
+                                         C.byref(S), C.byref(e2)))
+        self.S, self.e2 = S.value, e2.value
+        return self.S, self.e2
+
+    def smoothed(self):
+        out = np.zeros((self.H, self.W, 3), np.uint8)
+        self._ck(self.L.mcmc_overseg_get_smoothed(self.h, _ptr(out, np.uint8)))
+        return out
+
+    def edges(self):
+        n = self.L.mcmc_overseg_get_edges(self.h, None, None, None)
+        if n < 0:
+            self._ck(int(n))
+        a = np.zeros(n, np.int32); b = np.zeros(n, np.int32); w = np.zeros(n, np.float32)
+        self.L.mcmc_overseg_get_edges(self.h, _ptr(a, np.int32), _ptr(b, np.int32), _ptr(w, np.float32))
+        return a, b, w
+
+    def roots(self):
+        out = np.zeros(self.H * self.W, np.int32)
+        self._ck(self.L.mcmc_overseg_get_roots(self.h, _ptr(out, np.int32)))
+        return out
+
+    def labels(self):
+        out = np.zeros((self.H, self.W), np.uint16)
+        self._ck(self.L.mcmc_overseg_get_labels(self.h, _ptr(out, np.uint16)))
+        return out
+
+    def graph(self):
+        rp = np.zeros(self.S + 1, np.uint32); col = np.zeros(self.e2, np.uint32)
+        self._ck(self.L.mcmc_overseg_get_graph(self.h, _ptr(rp, np.uint32), _ptr(col, np.uint32)))
+        return rp, col
+
+    def device_buffers(self):
+        d = C.c_void_p(); l = C.c_void_p()
+        self._ck(self.L.mcmc_overseg_device_buffers(self.h, C.byref(d), C.byref(l)))
+        return d.value, l.value
+
+    def last_ms(self):
+        f = [C.c_float(0) for _ in range(4)]
+        self._ck(self.L.mcmc_overseg_last_ms(self.h, *[C.byref(x) for x in f]))
+        return dict(zip(("filter", "edges", "union_find", "graph"), (x.value for x in f)))

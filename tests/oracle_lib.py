@@ -29,7 +29,7 @@ f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
 def build():
     """Compile the oracle with gcc if the .so is missing or stale."""
     srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
-            if f.endswith(".c")]
+            if f.endswith((".c", ".cpp"))]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
@@ -76,6 +76,12 @@ def lib():
     L.orc_mv_chains_get_labels.argtypes = [C.c_void_p, C.c_int, u32p]
     L.orc_mv_chains_get_scalars.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.orc_mv_chains_get_planes.argtypes = [C.c_void_p, C.c_int, f64p]
+    L.orc_bilateral.argtypes = [i16p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p]
+    L.orc_create_edges.restype = C.c_longlong
+    L.orc_create_edges.argtypes = [i16p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, i32p, i32p, f32p]
+    L.orc_segment_graph.argtypes = [C.c_int, C.c_longlong, i32p, i32p, f32p, C.c_float, i32p]
+    L.orc_superpixels.argtypes = [i32p, C.c_int, C.c_int, u16p, C.POINTER(C.c_int), u32p, u32p, C.c_longlong,
+                                  C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -238,3 +244,36 @@ class MvChains:
             lib().orc_mv_chains_free(self.h)
         except Exception:
             pass
+
+
+# ---- front end (oracle/frontend_oracle.c, frontend_fh_oracle.cpp) --------------------------
+def bilateral(disp, colors, window=9, spatial_stdev=5.0, disparity_stdev=3.0):
+    H, W = disp.shape
+    out = np.zeros((H, W, 3), np.uint8)
+    rc = lib().orc_bilateral(np.ascontiguousarray(disp, np.int16), np.ascontiguousarray(colors, np.uint8), W, H,
+                             window, spatial_stdev, disparity_stdev, out)
+    return rc, out
+
+
+def create_edges(disp, smoothed, color_factor=1.0, disparity_factor=1.0, distance_factor=1.0):
+    H, W = disp.shape
+    a = np.zeros(4 * W * H, np.int32); b = np.zeros(4 * W * H, np.int32); w = np.zeros(4 * W * H, np.float32)
+    n = lib().orc_create_edges(np.ascontiguousarray(disp, np.int16), np.ascontiguousarray(smoothed, np.uint8), W, H,
+                               color_factor, disparity_factor, distance_factor, a, b, w)
+    return a[:n].copy(), b[:n].copy(), w[:n].copy()
+
+
+def segment_graph(nv, a, b, w, c):
+    root = np.zeros(nv, np.int32)
+    sets = lib().orc_segment_graph(nv, a.size, np.ascontiguousarray(a, np.int32), np.ascontiguousarray(b, np.int32),
+                                   np.ascontiguousarray(w, np.float32), float(c), root)
+    return sets, root
+
+
+def superpixels(root, W, H, col_cap=None):
+    label = np.zeros((H, W), np.uint16)
+    S = C.c_int(0); e2 = C.c_uint32(0)
+    cap = col_cap if col_cap is not None else 16 * W * H
+    rp = np.zeros(W * H + 1, np.uint32); col = np.zeros(cap, np.uint32)
+    rc = lib().orc_superpixels(np.ascontiguousarray(root, np.int32), W, H, label, C.byref(S), rp, col, cap, C.byref(e2))
+    return rc, label, S.value, rp[:S.value + 1].copy(), col[:e2.value].copy()
