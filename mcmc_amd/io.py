@@ -1,0 +1,89 @@
+"""On-disk formats of the reference, host side.
+
+* raw frame text, IO::readRawData / writeRawData (src/libraries/IO.cpp:6-48): one pixel per line in
+  row-major order, "<disparity>\\t<colour>\\n", colour packed r << 16 | g << 8 | b; read back into
+  int16 disparities and cv::Vec3b (B, G, R) colours.
+* over-segmentation parameters, IO::readSegmentationParams (IO.cpp:105-134): seven lines, value
+  then "# name": windowSize, spatialStdev, disparityStdev, weightThreshold, colorFactor,
+  disparityFactor, distanceFactor.
+* most-visited labelling as an image, Problem::printResults (Problem.cpp:305-370): one flat colour per
+  segment over the superpixels' pixels.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def write_raw_data(path, disp, colors):
+    """disp (H, W) int16, colors (H, W, 3) uint8 in B, G, R order."""
+    disp = np.asarray(disp); colors = np.asarray(colors)
+    packed = (colors[..., 2].astype(np.uint64) << 16) | (colors[..., 1].astype(np.uint64) << 8) | colors[..., 0].astype(np.uint64)
+    # writeRawData prints the short through a size_t (IO.cpp:39): a negative disparity wraps to 2^64 - |d|
+    d = disp.astype(np.int64).astype(np.uint64)
+    with open(path, "w") as f:
+        for a, b in zip(d.ravel().tolist(), packed.ravel().tolist()):
+            f.write(f"{a}\t{b}\n")
+
+
+def read_raw_data(path, width=640, height=480):
+    """Returns (disp int16 (H, W), colors uint8 (H, W, 3) B, G, R)."""
+    data = np.loadtxt(path, dtype=np.float64, ndmin=2)
+    if data.shape[0] < width * height or data.shape[1] < 2:
+        raise ValueError(f"{path}: expected {width * height} lines of two numbers, found {data.shape}")
+    data = data[: width * height]
+    disp = data[:, 0].astype(np.int64).astype(np.int16).reshape(height, width)       # (short) data(i, 0)
+    c = data[:, 1].astype(np.uint64)
+    colors = np.stack([(c & 0xFF), (c >> 8) & 0xFF, (c >> 16) & 0xFF], axis=1).astype(np.uint8).reshape(height, width, 3)
+    return disp, colors
+
+
+PARAM_NAMES = ("window_size", "spatial_stdev", "disparity_stdev", "weight_threshold", "color_factor",
+               "disparity_factor", "distance_factor")
+
+
+def read_segmentation_params(path):
+    """Dict with the seven OverSegmentationParameters; raises on a missing line, as the reference does."""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    if len(lines) < 7 or any(l.strip() == "" for l in lines[:7]):
+        raise ValueError("Missing line")
+    out = {}
+    for name, line in zip(PARAM_NAMES, lines[:7]):
+        h = line.find("#")
+        text = line[: h - 1] if h >= 0 else line          # substr(0, find('#') - 1), IO.cpp:121-127
+        out[name] = _atoi(text) if name in ("window_size", "weight_threshold") else _atof(text)
+    return out
+
+
+def _atof(t):
+    import re
+    m = re.match(r"\s*[-+]?(\d+\.?\d*([eE][-+]?\d+)?|\.\d+([eE][-+]?\d+)?)", t)
+    return float(m.group(0)) if m else 0.0
+
+
+def _atoi(t):
+    import re
+    m = re.match(r"\s*[-+]?\d+", t)
+    return int(m.group(0)) if m else 0
+
+
+def overseg_params(d):
+    """mcmc_overseg_params from the dict of read_segmentation_params."""
+    from . import host
+    p = host.OversegParams()
+    for k in PARAM_NAMES:
+        setattr(p, k, d[k])
+    return p
+
+
+def segments_image(label_map, segment_of_superpixel, seed=0):
+    """(H, W, 3) uint8 image: one colour per segment, black where the superpixel was dropped
+    (label 0xFFFF) -- the role of Problem::printResults' result image."""
+    seg = np.asarray(segment_of_superpixel)
+    lm = np.asarray(label_map).astype(np.int64)
+    rng = np.random.default_rng(seed)
+    palette = rng.integers(32, 256, (int(seg[seg != 0xFFFF].max(initial=0)) + 2, 3), dtype=np.uint8)
+    s = np.where(lm < seg.size, seg[np.minimum(lm, seg.size - 1)], 0xFFFF)
+    img = palette[np.minimum(s, palette.shape[0] - 1)]
+    img[s == 0xFFFF] = 0
+    return img
