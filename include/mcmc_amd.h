@@ -237,6 +237,21 @@ int mcmc_mv_fit_segment(mcmc_mv *mv, const uint32_t *members, int n_members, dou
 int mcmc_mv_pmerge(mcmc_mv *mv, const float *theta1, const float *theta2, const float *weights, int dim,
                    int n_pairs, double temperature, double *out);
 
+/* The world graph of several scans, built as the reference builds it: getPlanarAdjacencyGraph
+ * (GraphUtils.cpp:52-138) keeps an in-view neighbour pair when pMerge > in_view_threshold, and
+ * mergeNewScanGraph (GraphUtils.cpp:140-202) joins every vertex of a later scan with EVERY vertex
+ * already in the graph -- earlier vertices of its own scan included -- when pMerge > merge_threshold
+ * (SimpleSeg.cpp:409), then re-links the scan's in-view edges.  Vertices [0, n_first_scan) are the
+ * first scan, which only gets its in-view edges.  theta: V x dim full models (SPNode::getFullModel),
+ * in_row_ptr / in_col: in-view neighbour CSR over the same vertex ids (may be NULL).
+ * Output: symmetric CSR, neighbours ascending, prob = SPEdge::BernoulliProbability; e2_out is always
+ * set, MCMC_E_TOO_LARGE if it exceeds capacity (call again with room). */
+int mcmc_mv_build_world_graph(mcmc_mv *mv, int V, int dim, const float *theta, const float *weights,
+                              int n_first_scan, const uint32_t *in_row_ptr, const uint32_t *in_col,
+                              double in_view_threshold, double merge_threshold, double temperature,
+                              uint32_t *row_ptr_out, uint32_t *col_out, double *prob_out, uint32_t capacity,
+                              uint32_t *e2_out);
+
 /* MultiviewSegmentation(graph) per chain (MultiviewSegmentation.cpp:11-69):
  * Bernoulli every edge, connected components, fit every segment.  Philox key
  * (seed, chain_offset + k).  max_new_segments bounds the segments split

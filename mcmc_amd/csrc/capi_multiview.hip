@@ -217,6 +217,62 @@ int mcmc_mv_fit_segment(mcmc_mv* c, const uint32_t* members, int n, double* plan
     return MCMC_OK;
 }
 
+int mcmc_mv_build_world_graph(mcmc_mv* c, int V, int dim, const float* theta, const float* weights, int n_first_scan,
+                              const uint32_t* in_row_ptr, const uint32_t* in_col, double in_view_threshold,
+                              double merge_threshold, double temperature, uint32_t* row_ptr_out, uint32_t* col_out,
+                              double* prob_out, uint32_t capacity, uint32_t* e2_out)
+{
+    if (!c || !theta || !weights || !row_ptr_out || !e2_out || V <= 0 || V > 65535 || dim <= 0 || n_first_scan < 0 || n_first_scan > V)
+        return mfail(c, MCMC_E_BADARG, "mv_build_world_graph: bad argument");
+    const uint32_t in_e2 = in_row_ptr ? in_row_ptr[V] : 0u;
+    if (in_row_ptr) {
+        if (in_row_ptr[0] != 0 || (in_e2 && !in_col)) return mfail(c, MCMC_E_BADARG, "mv_build_world_graph: bad in-view graph");
+        for (int i = 0; i < V; ++i)
+            if (in_row_ptr[i + 1] < in_row_ptr[i]) return mfail(c, MCMC_E_BADARG, "mv_build_world_graph: in-view row_ptr not monotone");
+    }
+    MVCHK(c, hipSetDevice(c->device));
+    const int words = (V + 31) / 32;
+    float *dth = nullptr, *dw = nullptr; uint32_t *dbits = nullptr, *ddeg = nullptr, *drp = nullptr, *dcol = nullptr, *dirp = nullptr, *dic = nullptr;
+    double* dp = nullptr;
+    auto cleanup = [&]() { mvfree(dth); mvfree(dw); mvfree(dbits); mvfree(ddeg); mvfree(drp); mvfree(dcol); mvfree(dirp); mvfree(dic); mvfree(dp); };
+    hipError_t e = mvalloc(&dth, (size_t)V * dim);
+    if (e == hipSuccess) e = mvalloc(&dw, (size_t)dim);
+    if (e == hipSuccess) e = mvalloc(&dbits, (size_t)V * words);
+    if (e == hipSuccess) e = mvalloc(&ddeg, (size_t)V);
+    if (e == hipSuccess) e = mvalloc(&drp, (size_t)V + 1);
+    if (e == hipSuccess && in_e2) { e = mvalloc(&dirp, (size_t)V + 1); if (e == hipSuccess) e = mvalloc(&dic, (size_t)in_e2); }
+    if (e == hipSuccess) e = hipMemcpyAsync(dth, theta, (size_t)V * dim * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dw, weights, (size_t)dim * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && in_e2) {
+        e = hipMemcpyAsync(dirp, in_row_ptr, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dic, in_col, (size_t)in_e2 * 4, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(dbits, 0, (size_t)V * words * 4, c->stream);
+    if (e == hipSuccess) e = launch_mv_world_bits(dth, dw, dim, V, n_first_scan, dirp, dic, in_e2, in_view_threshold, merge_threshold,
+                                                  temperature, words, dbits, ddeg, c->stream);
+    std::vector<uint32_t> deg((size_t)V);
+    if (e == hipSuccess) e = hipMemcpyAsync(deg.data(), ddeg, (size_t)V * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { cleanup(); return mfail(c, MCMC_E_DEVICE, std::string("mv_build_world_graph: ") + hipGetErrorString(e)); }
+    row_ptr_out[0] = 0;
+    for (int i = 0; i < V; ++i) row_ptr_out[i + 1] = row_ptr_out[i] + deg[(size_t)i];
+    const uint32_t E2 = row_ptr_out[V];
+    *e2_out = E2;
+    if (E2 > capacity || (E2 && (!col_out || !prob_out))) { cleanup(); return mfail(c, MCMC_E_TOO_LARGE, "mv_build_world_graph: " + std::to_string(E2) + " directed edges exceed the capacity given"); }
+    if (E2) {
+        e = mvalloc(&dcol, (size_t)E2);
+        if (e == hipSuccess) e = mvalloc(&dp, (size_t)E2);
+        if (e == hipSuccess) e = hipMemcpyAsync(drp, row_ptr_out, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_mv_world_fill(dth, dw, dim, V, words, dbits, drp, temperature, dcol, dp, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(col_out, dcol, (size_t)E2 * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(prob_out, dp, (size_t)E2 * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    cleanup();
+    if (e != hipSuccess) return mfail(c, MCMC_E_DEVICE, std::string("mv_build_world_graph: ") + hipGetErrorString(e));
+    return MCMC_OK;
+}
+
 int mcmc_mv_pmerge(mcmc_mv* c, const float* t1, const float* t2, const float* w, int dim, int n, double T, double* out)
 {
     if (!c || !t1 || !t2 || !w || !out || dim <= 0 || n <= 0) return mfail(c, MCMC_E_BADARG, "mv_pmerge: bad argument");

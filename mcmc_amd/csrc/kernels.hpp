@@ -125,6 +125,11 @@ hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* o
 hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 size_t mv_chain_lds_bytes(int V);
+hipError_t launch_mv_world_bits(const float* th, const float* w, int dim, int V, int n0, const uint32_t* in_rowp,
+                                const uint32_t* in_col, uint32_t in_e2, double in_thr, double thr, double T, int words,
+                                uint32_t* bits, uint32_t* deg, hipStream_t st);
+hipError_t launch_mv_world_fill(const float* th, const float* w, int dim, int V, int words, const uint32_t* bits,
+                                const uint32_t* rowp, double T, uint32_t* col, double* prob, hipStream_t st);
 hipError_t launch_mv_pmerge(const float* t1, const float* t2, const float* w, int dim, int n, double T, double* out, hipStream_t st);
 
 }  // namespace mc

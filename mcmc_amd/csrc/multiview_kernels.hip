@@ -566,6 +566,100 @@ __global__ void mv_pmerge_kernel(const float* t1, const float* t2, const float* 
     out[i] = det_exp(-s * T / 2.0);
 }
 
+// ---- world graph (GraphUtils.cpp:52-138 getPlanarAdjacencyGraph, :140-202 mergeNewScanGraph) ----
+MC_D double pmerge_pair(const float* th, const float* w, int dim, int i, int j, double T)
+{
+    // theta1 = the lower id: |t2 - t1| is symmetric, so both directions get the same bits
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) {
+        double d = (double)th[(size_t)b * dim + k] - (double)th[(size_t)a * dim + k];
+        if (d < 0.0) d = -d;
+        const double e = (double)w[k] * d;
+        s += e * e;
+    }
+    return det_exp(-s * T / 2.0);
+}
+
+// every pair with a vertex of a later scan: one thread per (row, 32 columns)
+__global__ void mv_world_pairs_kernel(const float* th, const float* w, int dim, int V, int n0, int words, double thr,
+                                      double T, uint32_t* bits)
+{
+    const int wd = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int i = (int)blockIdx.y;
+    if (wd >= words) return;
+    uint32_t m = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int j = wd * 32 + b;
+        if (j >= V || j == i) continue;                       // no self loops (:166)
+        if ((i > j ? i : j) < n0) continue;                   // both in the first scan: in-view edges only
+        if (pmerge_pair(th, w, dim, i, j, T) > thr) m |= 1u << b;
+    }
+    if (m) atomicOr(bits + (size_t)i * words + wd, m);
+}
+
+// in-view neighbours (the superpixel graph of each scan): one thread per directed entry
+__global__ void mv_world_inview_kernel(const float* th, const float* w, int dim, int V, const uint32_t* rowp,
+                                       const uint32_t* col, uint32_t e2, int words, double thr, double T, uint32_t* bits)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= e2) return;
+    int lo = 0, hi = V;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowp[mid] <= e) lo = mid; else hi = mid; }
+    const int i = lo, j = (int)col[e];
+    if (j >= V || j == i) return;
+    if (pmerge_pair(th, w, dim, i, j, T) > thr) {
+        atomicOr(bits + (size_t)i * words + (j >> 5), 1u << (j & 31));
+        atomicOr(bits + (size_t)j * words + (i >> 5), 1u << (i & 31));
+    }
+}
+
+__global__ void mv_world_degree_kernel(const uint32_t* bits, int V, int words, uint32_t* deg)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= V) return;
+    uint32_t d = 0;
+    for (int k = 0; k < words; ++k) d += (uint32_t)__popc(bits[(size_t)i * words + k]);
+    deg[i] = d;
+}
+
+__global__ void mv_world_fill_kernel(const float* th, const float* w, int dim, int V, int words, const uint32_t* bits,
+                                     const uint32_t* rowp, double T, uint32_t* col, double* prob)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= V) return;
+    uint32_t e = rowp[i];
+    for (int k = 0; k < words; ++k) {
+        uint32_t m = bits[(size_t)i * words + k];
+        while (m) {
+            const int j = k * 32 + __ffs((int)m) - 1;
+            col[e] = (uint32_t)j; prob[e] = pmerge_pair(th, w, dim, i, j, T);
+            ++e; m &= m - 1u;
+        }
+    }
+}
+
+hipError_t launch_mv_world_bits(const float* th, const float* w, int dim, int V, int n0, const uint32_t* in_rowp,
+                                const uint32_t* in_col, uint32_t in_e2, double in_thr, double thr, double T, int words,
+                                uint32_t* bits, uint32_t* deg, hipStream_t st)
+{
+    hipLaunchKernelGGL(mv_world_pairs_kernel, dim3((unsigned)((words + 63) / 64), (unsigned)V), dim3(64), 0, st, th, w, dim, V, n0,
+                       words, thr, T, bits);
+    if (in_e2)
+        hipLaunchKernelGGL(mv_world_inview_kernel, dim3((in_e2 + 127) / 128), dim3(128), 0, st, th, w, dim, V, in_rowp, in_col,
+                           in_e2, words, in_thr, T, bits);
+    hipLaunchKernelGGL(mv_world_degree_kernel, dim3((unsigned)((V + 127) / 128)), dim3(128), 0, st, bits, V, words, deg);
+    return hipGetLastError();
+}
+
+hipError_t launch_mv_world_fill(const float* th, const float* w, int dim, int V, int words, const uint32_t* bits,
+                                const uint32_t* rowp, double T, uint32_t* col, double* prob, hipStream_t st)
+{
+    hipLaunchKernelGGL(mv_world_fill_kernel, dim3((unsigned)((V + 127) / 128)), dim3(128), 0, st, th, w, dim, V, words, bits, rowp,
+                       T, col, prob);
+    return hipGetLastError();
+}
+
 hipError_t launch_mv_pmerge(const float* t1, const float* t2, const float* w, int dim, int n, double T, double* out, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;

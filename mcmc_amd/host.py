@@ -104,6 +104,7 @@ def load():
         "mcmc_mv_get_vertex_moments": (i, [vp, vp]),
         "mcmc_mv_fit_segment": (i, [vp, vp, i, vp, C.POINTER(dbl), C.POINTER(dbl)]),
         "mcmc_mv_pmerge": (i, [vp, vp, vp, vp, i, i, dbl, vp]),
+        "mcmc_mv_build_world_graph": (i, [vp, i, i, vp, vp, i, vp, vp, dbl, dbl, dbl, vp, vp, vp, u32, C.POINTER(u32)]),
         "mcmc_mv_chains_init": (i, [vp, i, u32, u32, i, dbl]),
         "mcmc_mv_chains_run": (i, [vp, u64]),
         "mcmc_mv_chains_set_trace": (i, [vp, u64]),
@@ -376,6 +377,25 @@ class Multiview:
         self._ck(self.L.mcmc_mv_pmerge(self.h, _ptr(t1, np.float32), _ptr(t2, np.float32), _ptr(w, np.float32),
                                        dim, n, temperature, _ptr(out, np.float64)))
         return out
+
+    def build_world_graph(self, theta, weights, n_first_scan, in_row_ptr=None, in_col=None, in_view_threshold=0.01,
+                          merge_threshold=0.2, temperature=8.0):
+        """getPlanarAdjacencyGraph + mergeNewScanGraph on the GPU: returns (row_ptr, col, prob)."""
+        theta = np.ascontiguousarray(theta, np.float32); weights = np.ascontiguousarray(weights, np.float32)
+        V, dim = theta.shape
+        rp = np.zeros(V + 1, np.uint32); e2 = C.c_uint32(0)
+        irp = None if in_row_ptr is None else np.ascontiguousarray(in_row_ptr, np.uint32)
+        ic = None if in_col is None else np.ascontiguousarray(in_col, np.uint32)
+        args = (self.h, V, dim, _ptr(theta, np.float32), _ptr(weights, np.float32), n_first_scan, _ptr(irp, np.uint32),
+                _ptr(ic, np.uint32), in_view_threshold, merge_threshold, temperature)
+        rc = self.L.mcmc_mv_build_world_graph(*args, _ptr(rp, np.uint32), None, None, 0, C.byref(e2))
+        if rc not in (0, -6):
+            self._ck(rc)
+        col = np.zeros(e2.value, np.uint32); prob = np.zeros(e2.value, np.float64)
+        if e2.value:
+            self._ck(self.L.mcmc_mv_build_world_graph(*args, _ptr(rp, np.uint32), _ptr(col, np.uint32),
+                                                      _ptr(prob, np.float64), e2.value, C.byref(e2)))
+        return rp, col, prob
 
     def chains_init(self, n_chains, seed=1, chain_offset=0, max_new_segments=1024, split_prob=0.10):
         self._ck(self.L.mcmc_mv_chains_init(self.h, n_chains, seed, chain_offset, max_new_segments, split_prob))

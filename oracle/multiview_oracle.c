@@ -243,6 +243,47 @@ double orc_mv_pmerge(const float *t1, const float *t2, const float *w, int n, do
     return orc_det_exp(-s * temperature / 2.0);
 }
 
+/* World graph: getPlanarAdjacencyGraph (GraphUtils.cpp:52-138) + mergeNewScanGraph (:140-202).
+ * Edge {i, j}: in-view neighbours with pMerge > in_thr, or max(i, j) >= n0 (a vertex of a later
+ * scan against everything already in the graph, its own scan included) with pMerge > thr.
+ * theta1 of a pair is the lower id.  Returns the number of directed entries (CSR ascending);
+ * col / prob may be NULL to count. */
+long long orc_mv_world_graph(int V, int dim, const float *theta, const float *w, int n0, const uint32_t *in_rowp,
+                             const uint32_t *in_col, double in_thr, double thr, double T, uint32_t *row_ptr,
+                             uint32_t *col, double *prob)
+{
+    uint8_t *adj = (uint8_t *)calloc((size_t)V * V, 1);
+    for (int i = 0; i < V; ++i)
+        for (int j = i + 1; j < V; ++j)
+            if (j >= n0 && orc_mv_pmerge(theta + (size_t)i * dim, theta + (size_t)j * dim, w, dim, T) > thr)
+                adj[(size_t)i * V + j] = adj[(size_t)j * V + i] = 1;
+    if (in_rowp)
+        for (int i = 0; i < V; ++i)
+            for (uint32_t e = in_rowp[i]; e < in_rowp[i + 1]; ++e) {
+                const int j = (int)in_col[e];
+                if (j >= V || j == i) continue;
+                const int a = i < j ? i : j, b = i < j ? j : i;
+                if (orc_mv_pmerge(theta + (size_t)a * dim, theta + (size_t)b * dim, w, dim, T) > in_thr)
+                    adj[(size_t)i * V + j] = adj[(size_t)j * V + i] = 1;
+            }
+    long long e2 = 0;
+    for (int i = 0; i < V; ++i) {
+        row_ptr[i] = (uint32_t)e2;
+        for (int j = 0; j < V; ++j)
+            if (adj[(size_t)i * V + j]) {
+                if (col) col[e2] = (uint32_t)j;
+                if (prob) {
+                    const int a = i < j ? i : j, b = i < j ? j : i;
+                    prob[e2] = orc_mv_pmerge(theta + (size_t)a * dim, theta + (size_t)b * dim, w, dim, T);
+                }
+                ++e2;
+            }
+    }
+    row_ptr[V] = (uint32_t)e2;
+    free(adj);
+    return e2;
+}
+
 /* ------------------------------------------------------------------------- */
 /* chains                                                                     */
 /* ------------------------------------------------------------------------- */

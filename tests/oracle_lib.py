@@ -76,6 +76,9 @@ def lib():
     L.orc_mv_chains_get_labels.argtypes = [C.c_void_p, C.c_int, u32p]
     L.orc_mv_chains_get_scalars.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.orc_mv_chains_get_planes.argtypes = [C.c_void_p, C.c_int, f64p]
+    L.orc_mv_world_graph.restype = C.c_longlong
+    L.orc_mv_world_graph.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                     C.c_double, u32p, C.c_void_p, C.c_void_p]
     L.orc_bilateral.argtypes = [i16p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p]
     L.orc_create_edges.restype = C.c_longlong
     L.orc_create_edges.argtypes = [i16p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, i32p, i32p, f32p]
@@ -277,3 +280,16 @@ def superpixels(root, W, H, col_cap=None):
     rp = np.zeros(W * H + 1, np.uint32); col = np.zeros(cap, np.uint32)
     rc = lib().orc_superpixels(np.ascontiguousarray(root, np.int32), W, H, label, C.byref(S), rp, col, cap, C.byref(e2))
     return rc, label, S.value, rp[:S.value + 1].copy(), col[:e2.value].copy()
+
+
+def mv_world_graph(theta, weights, n0, in_row_ptr=None, in_col=None, in_thr=0.01, thr=0.2, T=8.0):
+    theta = np.ascontiguousarray(theta, np.float32); weights = np.ascontiguousarray(weights, np.float32)
+    V, dim = theta.shape
+    rp = np.zeros(V + 1, np.uint32)
+    irp = None if in_row_ptr is None else np.ascontiguousarray(in_row_ptr, np.uint32)
+    ic = None if in_col is None else np.ascontiguousarray(in_col, np.uint32)
+    pi = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    n = lib().orc_mv_world_graph(V, dim, theta, weights, n0, pi(irp), pi(ic), in_thr, thr, T, rp, None, None)
+    col = np.zeros(n, np.uint32); prob = np.zeros(n, np.float64)
+    lib().orc_mv_world_graph(V, dim, theta, weights, n0, pi(irp), pi(ic), in_thr, thr, T, rp, pi(col), pi(prob))
+    return rp, col, prob

@@ -246,3 +246,64 @@ def test_gpu_chains_c4_size_bit_exact(gpu_mv):
     # vertex sets stay a partition
     own = gpu_mv.labels(1)
     assert (own.max(axis=1) < gpu_mv.scalars()["n_segments"]).all()
+
+
+# ------------------------------------------------------------------ world graph
+def _world_inputs(seed=3, n0=30, n1=25, n2=20, dim=7):
+    rng = np.random.default_rng(seed)
+    V = n0 + n1 + n2
+    base = rng.uniform(-1, 1, (6, dim)).astype(np.float32)                 # six underlying planes
+    theta = (base[rng.integers(0, 6, V)] + rng.normal(0, 0.03, (V, dim))).astype(np.float32)
+    # in-view neighbour graphs: a ring plus a few chords inside each scan
+    pairs = set()
+    for lo, n in ((0, n0), (n0, n1), (n0 + n1, n2)):
+        for k in range(n):
+            pairs.add((lo + k, lo + (k + 1) % n)); pairs.add((lo + k, lo + (k + 5) % n))
+    nb = [set() for _ in range(V)]
+    for a, b in pairs:
+        if a != b:
+            nb[a].add(b); nb[b].add(a)
+    rp = np.zeros(V + 1, np.uint32); col = []
+    for i in range(V):
+        col += sorted(nb[i]); rp[i + 1] = len(col)
+    return theta, rp, np.array(col, np.uint32), n0
+
+
+def test_world_graph_against_numpy():
+    theta, irp, icol, n0 = _world_inputs()
+    V = theta.shape[0]
+    rp, col, prob = O.mv_world_graph(theta, DEFAULT_WEIGHTS, n0, irp, icol, in_thr=0.01, thr=0.2)
+    P = pmerge_np(theta[:, None, :], theta[None, :, :])                     # V x V
+    inview = np.zeros((V, V), bool)
+    src = np.repeat(np.arange(V), np.diff(irp.astype(np.int64)))
+    inview[src, icol] = True
+    later = np.maximum.outer(np.arange(V), np.arange(V)) >= n0             # a vertex of a later scan is involved
+    want = ((later & (P > 0.2)) | (inview & (P > 0.01))) & ~np.eye(V, dtype=bool)
+    got = np.zeros((V, V), bool)
+    gsrc = np.repeat(np.arange(V), np.diff(rp.astype(np.int64)))
+    got[gsrc, col] = True
+    margin = np.minimum(np.abs(P - 0.2), np.abs(P - 0.01)) > 1e-9          # away from the thresholds (libm vs det_exp)
+    assert np.array_equal(got[margin], want[margin])
+    assert np.array_equal(got, got.T)                                       # symmetric, like boost's undirectedS
+    assert np.allclose(prob, P[gsrc, col], rtol=1e-12)
+    for i in range(V):
+        r = col[rp[i]:rp[i + 1]]
+        assert (np.diff(r.astype(np.int64)) > 0).all() and i not in r       # ascending, no self loops (:166)
+    # first-scan vertices are joined to each other only through in-view edges (getPlanarAdjacencyGraph)
+    assert not (got[:n0, :n0] & ~inview[:n0, :n0]).any()
+    # later scans are joined to everything, their own scan included (mergeNewScanGraph iterates `original`)
+    assert (got[n0:, n0:] & ~inview[n0:, n0:]).any()
+
+
+@pytest.mark.gpu
+def test_gpu_world_graph_bit_exact(gpu_mv):
+    for seed, n0 in ((3, 30), (4, 0), (5, 75)):
+        theta, irp, icol, _ = _world_inputs(seed)
+        want = O.mv_world_graph(theta, DEFAULT_WEIGHTS, n0, irp, icol, in_thr=0.01, thr=0.2)
+        got = gpu_mv.build_world_graph(theta, DEFAULT_WEIGHTS, n0, irp, icol, 0.01, 0.2, 8.0)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert np.array_equal(got[2].view(np.uint64), want[2].view(np.uint64))
+    theta, irp, icol, n0 = _world_inputs(6)
+    want = O.mv_world_graph(theta, DEFAULT_WEIGHTS, n0)                     # no in-view graph
+    got = gpu_mv.build_world_graph(theta, DEFAULT_WEIGHTS, n0)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
