@@ -88,6 +88,37 @@ def cpu_baseline(sc, seed, seconds):
                       f"oracle/mcmc_oracle.c -O2 -ffp-contract=off, 1 thread, {cpu}"}
 
 
+def cpu_baseline_all_cores(sc, seed, seconds, threads):
+    """The same oracle, chains spread over host threads (ctypes releases the GIL): what SURVEY section 8d
+    asks for beside the single-threaded figure.  Each thread owns its chains; proposals / wall time."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import oracle_lib as O
+    S = sc.n_superpixels
+    fit, valid, _ = O.local_fit(O.moments(sc.disp, sc.label, S), sc.width, sc.height)
+    _, q = O.edge_probs(fit, valid, sc.row_ptr, sc.col)
+    burn, iters = 1000, 10000
+
+    def work(t):
+        n = 0
+        k = t
+        t_meas = 0.0
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            ch = O.Chains(fit, valid, sc.row_ptr, sc.col, q, 1, seed, chain_offset=1000 + k)
+            ch.run(burn, 0)
+            t1 = time.perf_counter()
+            ch.run(0, iters)
+            t_meas += time.perf_counter() - t1
+            n += iters
+            k += threads
+        return n / t_meas if t_meas > 0 else 0.0
+    with ThreadPoolExecutor(threads) as ex:
+        rate = sum(ex.map(work, range(threads)))       # threads run side by side for the whole window
+    return {"value": rate, "unit": "proposals/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} host threads side by side for {seconds:.0f} s, each running chains of (1000 burn-in + 10000 "
+                      f"measured) steps of the same C2 scene; sum of the threads' measured rates"}
+
+
 def k1_roofline(host, sc_list, n_frames, reps, device):
     """Moment-accumulation kernel on a batch of frames (C5 shape)."""
     W, H = sc_list[0].width, sc_list[0].height
@@ -145,7 +176,8 @@ def multiview_line(host, device, n_chains, steps):
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
             "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,
             "accept_rate": float(sc["n_accept"].sum()) / (2.0 * n_chains * steps),
-            "bound": "L2 / Infinity Cache (16 B x points of the four segments per proposal)"}
+            "bound": "latency of the per-chain component growth (first half of the split iteration); the L1 residual "
+                     "pass is evaluated for all chains vertex by vertex (f64 VALU, points read once per vertex block)"}
 
 
 def main():
@@ -247,6 +279,8 @@ def main():
             out["roofline"] = k1_roofline(host, scs, a.roofline_frames, a.roofline_reps, local)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, a.seed, a.cpu_seconds)
+            nthr = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(sc, a.seed, min(a.cpu_seconds, 6.0), min(nthr, 16))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -28,6 +28,9 @@ struct mcmc_mv {
     int *nseg = nullptr, *status = nullptr;
     unsigned long long *n_accept = nullptr, *n_split = nullptr, *n_skip = nullptr, *trace_hash = nullptr;
     uint8_t* trace = nullptr; double* trace_a = nullptr;
+    // split step: exchange buffers between the two halves of an iteration and the error kernel
+    void* ex_sh = nullptr; uint8_t *ex_inE = nullptr, *ex_need = nullptr; double* ex_err = nullptr;
+    int opt_split = -1;   // -1 automatic (split from 32 chains on), 0 fused, 1 split
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
 };
 
@@ -60,6 +63,8 @@ void free_chains(mcmc_mv* c)
     mvfree(c->cur); mvfree(c->own); mvfree(c->plane); mvfree(c->segP); mvfree(c->pvalid); mvfree(c->nseg);
     mvfree(c->status); mvfree(c->n_accept); mvfree(c->n_split); mvfree(c->n_skip); mvfree(c->trace_hash);
     mvfree(c->trace); mvfree(c->trace_a);
+    { uint8_t* p = static_cast<uint8_t*>(c->ex_sh); mvfree(p); c->ex_sh = nullptr; }
+    mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err);
     c->n = 0; c->trace_cap = 0; c->last_steps = 0;
 }
 MvGraph graph_of(const mcmc_mv* c)
@@ -316,6 +321,14 @@ int mcmc_mv_chains_init(mcmc_mv* c, int n_chains, uint32_t seed, uint32_t offset
     return MCMC_OK;
 }
 
+int mcmc_mv_set_option(mcmc_mv* c, const char* name, int value)
+{
+    if (!c || !name) return MCMC_E_BADARG;
+    if (std::string(name) == "split_step") c->opt_split = value;
+    else return mfail(c, MCMC_E_BADARG, std::string("mv_set_option: unknown option ") + name);
+    return MCMC_OK;
+}
+
 int mcmc_mv_chains_set_trace(mcmc_mv* c, uint64_t cap)
 {
     if (!c || c->n == 0) return mfail(c, MCMC_E_STATE, "mv_chains_set_trace: no chains");
@@ -337,8 +350,17 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     MvChainArgs a = chain_args_of(c);
     a.step0 = c->step; a.steps = steps;
     if (c->trace && steps <= c->trace_cap) { a.trace = c->trace; a.trace_a = c->trace_a; }
+    a.trace_stride = steps; a.trace_first = 0;
+    const bool split = c->opt_split == 1 || (c->opt_split < 0 && c->n >= 32);
+    if (split && !c->ex_err) {
+        const size_t N = (size_t)c->n, NV = N * c->V;
+        uint8_t* shp = nullptr;
+        MVCHK(c, mvalloc(&shp, N * mv_exchange_shared_bytes())); c->ex_sh = shp;
+        MVCHK(c, mvalloc(&c->ex_inE, NV)); MVCHK(c, mvalloc(&c->ex_need, NV)); MVCHK(c, mvalloc(&c->ex_err, NV * 4));
+    }
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
-    MVCHK(c, launch_mv_chain_run(graph_of(c), a, c->stream));
+    if (split) MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->stream));
+    else MVCHK(c, launch_mv_chain_run(graph_of(c), a, c->stream));
     MVCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     c->step += steps; c->last_steps = steps;

@@ -117,13 +117,17 @@ struct MvChainArgs {
     uint8_t* segP_valid;       // [C][seg_cap]
     int* nseg; int* status;
     unsigned long long *n_accept, *n_split, *n_skip, *trace_hash;
-    uint8_t* trace; double* trace_a;   // optional [C][steps]
+    uint8_t* trace; double* trace_a;   // optional [C][trace_stride], this launch writes from trace_first on
+    unsigned long long trace_stride, trace_first;
 };
 
 hipError_t launch_mv_vertex_moments(const MvGraph& g, double* out, hipStream_t st);
 hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* out, hipStream_t st);
 hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a, void* ex_sh, uint8_t* ex_inE, uint8_t* ex_need,
+                                     double* ex_err, hipStream_t st);
+size_t mv_exchange_shared_bytes();
 size_t mv_chain_lds_bytes(int V);
 hipError_t launch_mv_world_bits(const float* th, const float* w, int dim, int V, int n0, const uint32_t* in_rowp,
                                 const uint32_t* in_col, uint32_t in_e2, double in_thr, double thr, double T, int words,

@@ -220,6 +220,8 @@ MC_D uint32_t mv_draw_at(const MvRng& g, uint32_t d)
     return w == 0 ? r.x : (w == 1 ? r.y : (w == 2 ? r.z : r.w));
 }
 MC_D double mv_unit(uint32_t x) { return (double)x / 4294967295.0; }
+// lanes of one wave exchanging data through LDS: stops the compiler from forwarding or reordering across it
+MC_D void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 struct MvLds {
     uint16_t *cur, *own, *elist, *sv;
@@ -229,19 +231,21 @@ struct MvLds {
     MvShared* sh;
 };
 
-__host__ __device__ inline size_t mv_lds_bytes(int V)
+// with_err: the [4][V] residual table of the fused kernel (the split halves keep it in HBM, which lets five
+// workgroups share a CU instead of one)
+__host__ __device__ inline size_t mv_lds_bytes(int V, bool with_err)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return A(sizeof(MvShared)) + A((size_t)V * 32) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
+    return A(sizeof(MvShared)) + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
 }
 
-MC_D MvLds mv_carve(unsigned char* smem, int V)
+MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     MvLds L;
     size_t o = 0;
     L.sh = reinterpret_cast<MvShared*>(smem + o); o += A(sizeof(MvShared));
-    L.errv = reinterpret_cast<double*>(smem + o); o += A((size_t)V * 32);
+    L.errv = reinterpret_cast<double*>(smem + o); if (with_err) o += A((size_t)V * 32);
     L.se = reinterpret_cast<uint32_t*>(smem + o); o += A((size_t)V * 4);
     L.cur = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
     L.own = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = g.V;
-    MvLds L = mv_carve(smem, V);
+    MvLds L = mv_carve(smem, V, false);
     const int chain = (int)blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int v = tid; v < V; v += kMvThreads) L.cur[v] = 0xFFFFu;
@@ -313,12 +317,25 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
     }
 }
 
-// PatternedMatcher.cpp:58-130, `steps` iterations per launch
-__global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvChainArgs a)
+// Exchange between the three kernels of a split step (MODE 1 -> mv_errors_kernel -> MODE 2)
+struct MvExchange {
+    MvShared* sh;       // [C]
+    uint8_t* inE;       // [C][V] the grown set
+    uint8_t* need;      // [V][C] bit k: the L1 residual of vertex v under plane k of this chain is wanted
+    double* err;        // [C][4][V]
+};
+
+// PatternedMatcher.cpp:58-130.  MODE 0: `steps` whole iterations per launch, one workgroup per chain, the L1
+// pass included (every chain streams the points of its four segments through L2 by itself).
+// MODE 1 / MODE 2: the first / second half of ONE iteration; between them mv_errors_kernel evaluates the
+// L1 residuals of all chains vertex by vertex, so a vertex's points are read once for every chain that
+// needs them instead of once per chain.  Same arithmetic in the same order, hence the same bits.
+template <int MODE>
+__global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = g.V;
-    MvLds L = mv_carve(smem, V);
+    MvLds L = mv_carve(smem, V, MODE == 0);
     MvShared* sh = L.sh;
     const int chain = (int)blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -328,6 +345,14 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     double* segP = a.segP + (size_t)chain * a.seg_cap;
     uint8_t* pvalid = a.segP_valid + (size_t)chain * a.seg_cap;
     for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
+    if (MODE == 2) {
+        // second half: the grown set, the shared block and the residuals come from the first half and the error kernel
+        for (int v = tid; v < V; v += kMvThreads) L.inE[v] = x.inE[(size_t)chain * V + v];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(x.sh + chain);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sh);
+        for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += kMvThreads) dst[k] = src[k];
+        L.errv = x.err + (size_t)chain * 4 * V;
+    }
     int nseg = a.nseg[chain], status = a.status[chain];
     unsigned long long n_accept = a.n_accept[chain], n_split = a.n_split[chain], n_skip = a.n_skip[chain];
     unsigned long long trace_hash = a.trace_hash[chain];
@@ -336,7 +361,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     for (unsigned long long ts = 0; ts < a.steps; ++ts) {
         const unsigned long long t = a.step0 + ts;
         if (status != 0) {
-            if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.steps + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.steps + ts] = 0.0; }
+            if (MODE != 2 && tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
+            if (MODE == 1) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
             continue;
         }
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
@@ -346,9 +372,28 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         // top of the stack at once: candidates get the draws nd, nd+1, ... in edge order; the first
         // success is descended into (draws of later lanes are not consumed: the scan resumes after that
         // edge when the recursion returns, exactly as the sequential loop does).
-        if (wave == 0) {
+        if (MODE != 2 && wave == 0) {
             uint32_t nd = 0;
-            const uint32_t start = mv_draw_at(rg, nd++) % (uint32_t)V;
+            // draws nd, nd + 1, ... come from batches of 256 kept in LDS: one Philox call per lane per batch
+            int batch = -1;
+            auto draws_for = [&](uint32_t d, bool want) -> uint32_t {     // d = this lane's draw index
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nd);
+                uint32_t r = 0;
+                for (int b = (int)(d0 >> 8); b <= (int)((d0 + 63u) >> 8); ++b) {
+                    if (!__ballot(want && (int)(d >> 8) == b)) continue;
+                    if (b != batch) {
+                        wave_lds_fence();
+                        const u32x4 c = { rg.lo, rg.hi, (uint32_t)b * 64u + (uint32_t)lane, kPhiloxTagMv };
+                        const u32x4 w4 = philox4x32_10(c, rg.k0, rg.k1);
+                        sh->rbuf[lane] = w4.x; sh->rbuf[64 + lane] = w4.y; sh->rbuf[128 + lane] = w4.z; sh->rbuf[192 + lane] = w4.w;
+                        wave_lds_fence();
+                        batch = b;
+                    }
+                    if (want && (int)(d >> 8) == b) r = sh->rbuf[d & 255u];
+                }
+                return r;
+            };
+            const uint32_t start = draws_for(nd, true) % (uint32_t)V; nd++;
             uint32_t nE = 1; int sp = 1;
             if (lane == 0) { L.inE[start] = 1; L.elist[0] = (uint16_t)start; L.sv[0] = (uint16_t)start; L.se[0] = g.rowp[start]; }
             const uint16_t cs = L.cur[start];
@@ -360,12 +405,13 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 while (e0 < e1) {
                     const uint32_t e = e0 + (uint32_t)lane;
                     uint32_t j = 0;
+                    double qe = 0.0;
                     bool cand = false;
-                    if (e < e1) { j = g.col[e]; cand = L.cur[j] == cs && L.inE[j] == 0; }
+                    if (e < e1) { j = g.col[e]; qe = g.q[e]; cand = L.cur[j] == cs && L.inE[j] == 0; }
                     const uint64_t m = __ballot(cand);
                     if (m == 0) { e0 += kWave; continue; }
-                    bool ok = false;
-                    if (cand) ok = mv_unit(mv_draw_at(rg, nd + (uint32_t)mbcnt(m))) <= g.q[e];
+                    const uint32_t dr = draws_for(nd + (uint32_t)mbcnt(m), cand);
+                    const bool ok = cand && mv_unit(dr) <= qe;
                     const uint64_t sm = __ballot(ok);
                     if (sm == 0) { nd += (uint32_t)__popcll((unsigned long long)m); e0 += kWave; continue; }
                     const int first = __ffsll((unsigned long long)sm) - 1;
@@ -376,13 +422,14 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                         L.se[sp - 1] = e0 + (uint32_t)first + 1u;
                         L.sv[sp] = (uint16_t)js; L.se[sp] = g.rowp[js];
                     }
+                    wave_lds_fence();
                     nE++; sp++;
                     descended = true;
                     break;
                 }
                 if (!descended) sp--;
             }
-            const double moveType = mv_unit(mv_draw_at(rg, nd++));
+            const double moveType = mv_unit(draws_for(nd, true)); nd++;
             if (lane == 0) {
                 sh->start = start; sh->orig = L.own[start]; sh->nE = nE; sh->nd = nd;
                 int kind = 0;
@@ -397,13 +444,17 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         const uint32_t nE = sh->nE, orig = sh->orig;
         int kind = sh->kind;
         if (kind == 3) {
+            if (MODE == 2) break;                  // frozen and traced by the first half
             status = -6;
             for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
-            if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.steps + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.steps + ts] = 0.0; }
+            if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
+            if (MODE == 1) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
             __syncthreads();
             continue;
         }
-        if (kind == 1) {
+        if (MODE == 2) {
+            // nothing: the proposal was made by the first half
+        } else if (kind == 1) {
             // addNewSegment (MultiviewSegmentation.cpp:85-110): the vertices really move
             const uint32_t tg = sh->target;
             for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) {
@@ -465,7 +516,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 if (k == 2) return o == orig && !L.inE[v];
                 return o == target || L.inE[v];
             };
-            {
+            if (MODE != 2) {
                 double m[10], p5[5];
                 int cached = 0;
                 if (wave == 0) {
@@ -497,6 +548,17 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             __syncthreads();
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
+            if (MODE == 1) {
+                for (int v = tid; v < V; v += kMvThreads) {
+                    const uint32_t o = L.own[v];
+                    const bool ie = L.inE[v] != 0;
+                    const uint32_t nb4 = (uint32_t)(!h0 && o == orig) | ((uint32_t)(!h1 && o == target) << 1) |
+                                         ((uint32_t)(o == orig && !ie) << 2) | ((uint32_t)(o == target || ie) << 3);
+                    x.need[(size_t)v * a.n_chains + chain] = (uint8_t)nb4;
+                    x.inE[(size_t)chain * V + v] = L.inE[v];
+                }
+            }
+            if (MODE == 0)
             for (int v = wave; v < V; v += kMvWaves) {
                 const uint32_t o = L.own[v];
                 const bool ie = L.inE[v] != 0;
@@ -511,7 +573,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             }
             __syncthreads();
             // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
-            if (!sh->have[wave]) {
+            if (MODE != 1 && !sh->have[wave]) {
                 double part = 0.0;
                 for (int v = lane; v < V; v += kWave) if (member(wave, v)) part += L.errv[(size_t)wave * V + v];
                 const double err = wave_sum_f64(part);
@@ -522,6 +584,15 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 }
             }
             __syncthreads();
+        }
+        if (MODE == 1) {
+            // first half done: hand the shared block over (a skipped proposal wants no residuals)
+            if (kind == 2) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
+            __syncthreads();
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(x.sh + chain);
+            for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += kMvThreads) dst[k] = src[k];
+            continue;
         }
         // ---- phase 5: computeProposalRatio + accept (MultiviewSegmentation.cpp:270-274; PatternedMatcher.cpp:111-112) ----
         uint8_t flags = kind == 1 ? 2 : (kind == 2 ? 4 : 0);
@@ -535,19 +606,52 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         }
         trace_hash = mix64(mix64(trace_hash ^ ((uint64_t)flags | ((uint64_t)sh->start << 8) | ((uint64_t)nE << 32))) ^ d2u(av));
         if (tid == 0 && a.trace) {
-            a.trace[(size_t)chain * a.steps + ts] = flags;
-            if (a.trace_a) a.trace_a[(size_t)chain * a.steps + ts] = av;
+            a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = flags;
+            if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = av;
         }
-        // clear the step's flags
-        for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
-        if (kind != 1) for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
+        // clear the step's flags (the halves of a split step start from cleared LDS instead)
+        if (MODE == 0) {
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
+            if (kind != 1) for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
+        }
         __syncthreads();
     }
-    for (int v = tid; v < V; v += kMvThreads) gown[v] = L.own[v];
+    if (MODE != 2) for (int v = tid; v < V; v += kMvThreads) gown[v] = L.own[v];
     if (tid == 0) {
-        a.nseg[chain] = nseg; a.status[chain] = status;
-        a.n_accept[chain] = n_accept; a.n_split[chain] = n_split; a.n_skip[chain] = n_skip;
-        a.trace_hash[chain] = trace_hash;
+        if (MODE != 2) { a.nseg[chain] = nseg; a.status[chain] = status; a.n_split[chain] = n_split; }
+        if (MODE != 1) { a.n_accept[chain] = n_accept; a.n_skip[chain] = n_skip; a.trace_hash[chain] = trace_hash; }
+    }
+}
+
+// L1 residuals of one split step: wave = (vertex, block of chains).  The wave reads which chains want the vertex
+// (64 codes per load, chain-minor layout), and for every wanted (chain, plane) runs the same per-vertex loop
+// as the fused kernel -- the vertex's points stay in L1 / L2 for all of them.
+constexpr int kErrChainsPerBlock = 256;
+__global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int v = (int)(blockIdx.x * kMvWaves + (threadIdx.x >> 6));
+    if (v >= g.V) return;
+    const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
+    const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
+    for (int cb = c0; cb < c1; cb += kWave) {
+        const int cc = cb + lane;
+        const uint32_t code = cc < c1 ? (uint32_t)x.need[(size_t)v * n_chains + cc] : 0u;
+        uint64_t m = __ballot(code != 0u);
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1ull;
+            const int chain = cb + l;
+            const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)code, l);
+            const MvShared* sh = x.sh + chain;
+            double* out = x.err + (size_t)chain * 4 * g.V;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((cd >> k) & 1u)) continue;
+                const double r = vertex_error(g.pts, b, e, sh->pl[k], lane);
+                if (lane == 0) out[(size_t)k * g.V + v] = r;
+            }
+        }
     }
 }
 
@@ -677,14 +781,20 @@ hipError_t launch_mv_vertex_moments(const MvGraph& g, double* out, hipStream_t s
     return hipGetLastError();
 }
 
-size_t mv_chain_lds_bytes(int V) { return mv_lds_bytes(V); }
+size_t mv_chain_lds_bytes(int V) { return mv_lds_bytes(V, true); }
 
 static hipError_t mv_set_lds_attr()
 {
     static bool done = false;
     if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_init_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -710,7 +820,7 @@ hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStrea
 {
     hipError_t e = mv_set_lds_attr();
     if (e != hipSuccess) return e;
-    const size_t bytes = mv_lds_bytes(g.V);
+    const size_t bytes = mv_lds_bytes(g.V, false);
     if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mv_chain_init_kernel, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a);
     return hipGetLastError();
@@ -720,9 +830,32 @@ hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream
 {
     hipError_t e = mv_set_lds_attr();
     if (e != hipSuccess) return e;
-    const size_t bytes = mv_lds_bytes(g.V);
+    const size_t bytes = mv_lds_bytes(g.V, true);
     if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mv_chain_run_kernel, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a);
+    MvExchange x{};
+    hipLaunchKernelGGL(mv_chain_run_kernel<0>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+    return hipGetLastError();
+}
+
+size_t mv_exchange_shared_bytes() { return sizeof(MvShared); }
+
+// the same `steps` iterations as three kernels per iteration (see mv_chain_run_kernel)
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, void* ex_sh, uint8_t* ex_inE, uint8_t* ex_need,
+                                     double* ex_err, hipStream_t st)
+{
+    hipError_t e = mv_set_lds_attr();
+    if (e != hipSuccess) return e;
+    const size_t bytes = mv_lds_bytes(g.V, false);
+    if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
+    MvExchange x{ reinterpret_cast<MvShared*>(ex_sh), ex_inE, ex_need, ex_err };
+    const dim3 egrid((unsigned)((g.V + kMvWaves - 1) / kMvWaves), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
+    for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
+        MvChainArgs a = a0;
+        a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
+        hipLaunchKernelGGL(mv_chain_run_kernel<1>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+        hipLaunchKernelGGL(mv_errors_kernel, egrid, dim3(kMvThreads), 0, st, g, a.n_chains, x);
+        hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+    }
     return hipGetLastError();
 }
 

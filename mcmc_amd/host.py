@@ -107,6 +107,7 @@ def load():
         "mcmc_mv_build_world_graph": (i, [vp, i, i, vp, vp, i, vp, vp, dbl, dbl, dbl, vp, vp, vp, u32, C.POINTER(u32)]),
         "mcmc_mv_chains_init": (i, [vp, i, u32, u32, i, dbl]),
         "mcmc_mv_chains_run": (i, [vp, u64]),
+        "mcmc_mv_set_option": (i, [vp, C.c_char_p, i]),
         "mcmc_mv_chains_set_trace": (i, [vp, u64]),
         "mcmc_mv_chains_get_trace": (i, [vp, vp, vp]),
         "mcmc_mv_chains_get_labels": (i, [vp, i, vp]),
@@ -400,6 +401,9 @@ class Multiview:
     def chains_init(self, n_chains, seed=1, chain_offset=0, max_new_segments=1024, split_prob=0.10):
         self._ck(self.L.mcmc_mv_chains_init(self.h, n_chains, seed, chain_offset, max_new_segments, split_prob))
         self.n_chains = n_chains
+
+    def set_option(self, name, value):
+        self._ck(self.L.mcmc_mv_set_option(self.h, name.encode(), int(value)))
 
     def chains_set_trace(self, cap):
         self._ck(self.L.mcmc_mv_chains_set_trace(self.h, cap))

@@ -307,3 +307,31 @@ def test_gpu_world_graph_bit_exact(gpu_mv):
     want = O.mv_world_graph(theta, DEFAULT_WEIGHTS, n0)                     # no in-view graph
     got = gpu_mv.build_world_graph(theta, DEFAULT_WEIGHTS, n0)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+def test_gpu_split_step_equals_fused_and_oracle(gpu_mv, mv_small):
+    """The three-kernel iteration (residuals of all chains evaluated vertex by vertex) gives the bits of
+    the fused kernel and of the oracle, capacity freeze included."""
+    mv = mv_small
+    _load(gpu_mv, mv)
+    gpu_mv.vertex_moments()
+    res = {}
+    for mode in (0, 1):
+        gpu_mv.set_option("split_step", mode)
+        gpu_mv.chains_init(6, seed=7, max_new_segments=3, split_prob=0.3)
+        gpu_mv.chains_set_trace(40)
+        gpu_mv.chains_run(25); f1, a1 = gpu_mv.trace()
+        gpu_mv.chains_run(15); f2, a2 = gpu_mv.trace()
+        res[mode] = (np.concatenate([f1, f2], 1), np.concatenate([a1, a2], 1), gpu_mv.scalars(), gpu_mv.labels(1))
+    gpu_mv.set_option("split_step", -1)
+    ch = O.MvChains(mv, 6, seed=7, max_new_segments=3, split_prob=0.3)
+    f, a = ch.run(40)
+    s = ch.scalars()
+    for mode in (0, 1):
+        gf, ga, gs, gl = res[mode]
+        assert np.array_equal(gf, f) and np.array_equal(ga.view(np.uint64), a.view(np.uint64)), mode
+        for k in ("n_accept", "n_split", "n_skip", "trace_hash", "n_segments", "status"):
+            assert np.array_equal(gs[k], s[k]), (mode, k)
+        assert np.array_equal(gl, ch.labels(1)), mode
+    assert (s["status"] == -6).any()          # the case covers a frozen chain

@@ -1,0 +1,15 @@
+"""Path B at C4 size for rocprofv3: the three kernels of the split iteration (or the fused one with FUSED=1)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcmc_amd import host
+from mcmc_amd.scene import make_multiview
+mv = make_multiview(n_views=3, width=640, height=480, n_planes=8, n_superpixels=500, seed=4)
+m = host.Multiview()
+m.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, mv.q)
+m.vertex_moments()
+if os.environ.get("FUSED"):
+    m.set_option("split_step", 0)
+m.chains_init(int(os.environ.get("CHAINS", 1024)), seed=1)
+m.chains_run(2)
+m.chains_run(int(os.environ.get("STEPS", 10)))
+print("ms per launch", m.last_run_ms())
