@@ -35,6 +35,7 @@ struct Chains {
     int* status = nullptr;
     uint8_t* trace = nullptr;
     unsigned long long trace_cap = 0, last_steps = 0;
+    unsigned long long* slots_g = nullptr; size_t slots_cap = 0;
 };
 
 }  // namespace
@@ -102,7 +103,7 @@ void free_chains(Chains& h)
     dfree(h.segC); dfree(h.energy); dfree(h.best_energy); dfree(h.tmp_energy);
     dfree(h.state_hash); dfree(h.trace_hash); dfree(h.n_accept); dfree(h.n_case);
     dfree(h.visit_hash); dfree(h.visit_count); dfree(h.overflow); dfree(h.top_count); dfree(h.top_hash);
-    dfree(h.status); dfree(h.trace);
+    dfree(h.status); dfree(h.trace); dfree(h.slots_g);
     h = Chains();
 }
 
@@ -543,6 +544,15 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
     int s_used = 0, e_used = 0;
     const int frames_needed = (h.n + h.cpf - 1) / h.cpf;
     for (int f = 0; f < frames_needed; ++f) { s_used = std::max(s_used, c->h_S[f]); e_used = std::max(e_used, (int)c->h_E2[f]); }
+    {
+        const size_t per_chain = chain_run_global_slots(a, s_used, e_used);
+        if (per_chain * (size_t)h.n > h.slots_cap) {
+            dfree(h.slots_g);
+            HIPCHK(c, dalloc(&h.slots_g, per_chain * (size_t)h.n));
+            h.slots_cap = per_chain * (size_t)h.n;
+        }
+        a.slots_g = h.slots_g;
+    }
     {
         Timer t(c, K_CHAIN);
         hipError_t e = launch_chain_run(a, s_used, e_used, c->stream, &c->chain_variant);

@@ -157,6 +157,8 @@ struct LdsLayout {
 // queue slots: one per node of the component, plus one per further 8 neighbours of a node
 __host__ __device__ inline size_t queue_slots(int S, int E2) { return (size_t)S + (size_t)E2 / 8 + 8; }
 
+// The FIFO lives in LDS next to the tables; frames whose tables do not fit keep it in HBM too (a.slots_g), which
+// leaves room for several chains per workgroup.
 __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -172,7 +174,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     const size_t NW = (size_t)(S + 31) / 32;
     size_t w = 0;
     L.w_label = w; w += A((size_t)S * 2);
-    L.w_slots = w; w += A(queue_slots(S, E2) * 8);
+    L.w_slots = w; if (tab_lds) w += A(queue_slots(S, E2) * 8);
     L.w_cl = w; w += A((size_t)S * 4);
     L.w_nflag = w; w += A((size_t)S);
     L.w_rbits = w; w += A(NW * 4);
@@ -276,7 +278,12 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
     uint16_t* label = reinterpret_cast<uint16_t*>(wbase + L.w_label);
     // FIFO of the growth: .x = node | entries << 16 | part << 24, .y = first CSR entry of the part
-    uint2* slots = reinterpret_cast<uint2*>(wbase + L.w_slots);
+    uint2* slots = TAB_LDS ? reinterpret_cast<uint2*>(wbase + L.w_slots)
+                           : reinterpret_cast<uint2*>(a.slots_g) + (size_t)chain * queue_slots(s_lds, e2_lds);
+    // appends to the FIFO are read by other lanes of this wave in a later pass
+    auto queue_fence = [&]() {
+        if constexpr (TAB_LDS) wave_fence(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    };
     uint32_t* cl = reinterpret_cast<uint32_t*>(wbase + L.w_cl);          // kFree, or in the component
     uint8_t* nflag = wbase + L.w_nflag;                                   // by label: 1 = neighbouring segment
     uint32_t* nflagw = reinterpret_cast<uint32_t*>(wbase + L.w_nflag);
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     slots[pp] = make_uint2(start | (min(8u, d0 - 8u * pp) << 16) | (pp << 24), rs0 + 8u * pp);
                 if (lane == 0) cl[start] = 0u;
                 qt = parts0;
-                wave_fence();
+                queue_fence();
             }
             const uint32_t g8 = (uint32_t)lane >> 3, s8 = (uint32_t)lane & 7u;
             while (head < qt) {
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                         qt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     }
                     qn += (uint32_t)__popcll((unsigned long long)wm);
-                    wave_fence();
+                    queue_fence();
                 }
                 head += K;
                 if constexpr (PROF) pacc[15] += 1;
@@ -825,6 +832,18 @@ static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size
     return hipGetLastError();
 }
 
+// slots per chain of the HBM FIFO the launch will use, 0 if the tables (and the FIFO) fit LDS
+size_t chain_run_global_slots(const ChainArgs& a, int s_used_max, int e2_used_max)
+{
+    const size_t cap = kLdsLimit - 64;
+    const int wpbs[3] = { 4, 2, 1 };
+    for (int wi = 0; wi < 3; ++wi) {
+        if (a.chains_per_frame % wpbs[wi]) continue;
+        if (make_layout(s_used_max, e2_used_max, wpbs[wi], true).total <= cap) return 0;
+    }
+    return queue_slots(s_used_max, e2_used_max);
+}
+
 hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out)
 {
     const size_t cap = kLdsLimit - 64;
@@ -835,6 +854,7 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
             if (a.chains_per_frame % wpb) continue;
             const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0);
             if (L.total > cap) continue;
+            if (!tab && !a.slots_g) return hipErrorInvalidValue;
             if (variant_out) *variant_out = tab * 10 + wpb;
             if (tab) {
                 if (wpb == 4) return launch_variant<4, true>(a, s_used_max, e2_used_max, L.total, st);

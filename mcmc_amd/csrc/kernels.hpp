@@ -73,6 +73,7 @@ struct ChainArgs {
     unsigned long long* marg;  // [F][s_max][lmax]
     unsigned long long* dwell; // [C] post-burn-in steps spent in the current state, not yet booked
     uint8_t* trace; unsigned long long trace_stride; // optional
+    unsigned long long* slots_g; // [C][queue slots] FIFO of the growth when the frame's tables do not fit LDS (else unused)
     unsigned long long* prof;  // optional: 12 per-phase cycle sums (diagnostic build of the 4-wave LDS variant)
     int hcap, lmax;
 };
@@ -89,6 +90,7 @@ hipError_t launch_selftest_philox(const uint32_t* ck, uint32_t* out, hipStream_t
 // chain kernel: returns hipErrorInvalidValue if the per-chain state does not fit LDS
 hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st);
 hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out);
+size_t chain_run_global_slots(const ChainArgs& a, int s_used_max, int e2_used_max);
 hipError_t launch_chain_energy(const ChainArgs& a, double* out, hipStream_t st);
 hipError_t launch_canonical_labels(const uint16_t* src, const uint8_t* valid, const int* S, int s_max,
                                    int n_chains, int chains_per_frame, uint16_t* dst, hipStream_t st);
