@@ -152,7 +152,7 @@ def k1_roofline(host, sc_list, n_frames, reps, device):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": "sp_moments_kernel", "workload": f"{n_frames} frames x {W}x{H} (C5 batch)",
+    return {"bound": "hbm", "kernel": "sp_moments_lr_kernel", "workload": f"{n_frames} frames x {W}x{H} (C5 batch)",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg, "min_launch_ms": float(np.min(ms)),
             "launches": reps, "traffic": traffic}
