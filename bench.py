@@ -176,8 +176,8 @@ def multiview_line(host, device, n_chains, steps):
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
             "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,
             "accept_rate": float(sc["n_accept"].sum()) / (2.0 * n_chains * steps),
-            "bound": "latency of the per-chain component growth (first half of the split iteration); the L1 residual "
-                     "pass is evaluated for all chains vertex by vertex (f64 VALU, points read once per vertex block)"}
+            "bound": "f64 VALU of the L1 residual pass (evaluated for all chains vertex by vertex, points read once per "
+                     "vertex block); the per-chain growth is breadth first over four waves"}
 
 
 def main():

@@ -226,7 +226,8 @@ MC_D void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront
 struct MvLds {
     uint16_t *cur, *own, *elist, *sv;
     uint8_t *inE, *nb;
-    uint32_t* se;
+    uint32_t* se;       // [V] claim words of the growth (0 = free)
+    uint32_t* cand;     // [4][128] candidate edges per wave
     double* errv;       // [4][V]
     MvShared* sh;
 };
@@ -236,7 +237,7 @@ struct MvLds {
 __host__ __device__ inline size_t mv_lds_bytes(int V, bool with_err)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return A(sizeof(MvShared)) + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
+    return A(sizeof(MvShared)) + 2048 + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
 }
 
 MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
@@ -245,6 +246,7 @@ MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
     MvLds L;
     size_t o = 0;
     L.sh = reinterpret_cast<MvShared*>(smem + o); o += A(sizeof(MvShared));
+    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += 2048;
     L.errv = reinterpret_cast<double*>(smem + o); if (with_err) o += A((size_t)V * 32);
     L.se = reinterpret_cast<uint32_t*>(smem + o); o += A((size_t)V * 4);
     L.cur = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     double* planes = a.plane + (size_t)chain * a.seg_cap * 5;
     double* segP = a.segP + (size_t)chain * a.seg_cap;
     uint8_t* pvalid = a.segP_valid + (size_t)chain * a.seg_cap;
-    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
+    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; L.se[v] = 0u; }
     if (MODE == 2) {
         // second half: the grown set, the shared block and the residuals come from the first half and the error kernel
         for (int v = tid; v < V; v += kMvThreads) L.inE[v] = x.inE[(size_t)chain * V + v];
@@ -366,72 +368,63 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             continue;
         }
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
-        // ---- phase 1a (wave 0): start vertex, DFS growth, move type ----
-        // getNewConnectedSet (MultiviewSegmentation.cpp:207-257) is a recursive DFS with one draw per
-        // same-segment neighbour that is not yet in the set.  The wave scans 64 out-edges of the vertex on
-        // top of the stack at once: candidates get the draws nd, nd+1, ... in edge order; the first
-        // success is descended into (draws of later lanes are not consumed: the scan resumes after that
-        // edge when the recursion returns, exactly as the sequential loop does).
-        if (MODE != 2 && wave == 0) {
-            uint32_t nd = 0;
-            // draws nd, nd + 1, ... come from batches of 256 kept in LDS: one Philox call per lane per batch
-            int batch = -1;
-            auto draws_for = [&](uint32_t d, bool want) -> uint32_t {     // d = this lane's draw index
-                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nd);
-                uint32_t r = 0;
-                for (int b = (int)(d0 >> 8); b <= (int)((d0 + 63u) >> 8); ++b) {
-                    if (!__ballot(want && (int)(d >> 8) == b)) continue;
-                    if (b != batch) {
-                        wave_lds_fence();
-                        const u32x4 c = { rg.lo, rg.hi, (uint32_t)b * 64u + (uint32_t)lane, kPhiloxTagMv };
-                        const u32x4 w4 = philox4x32_10(c, rg.k0, rg.k1);
-                        sh->rbuf[lane] = w4.x; sh->rbuf[64 + lane] = w4.y; sh->rbuf[128 + lane] = w4.z; sh->rbuf[192 + lane] = w4.w;
-                        wave_lds_fence();
-                        batch = b;
-                    }
-                    if (want && (int)(d >> 8) == b) r = sh->rbuf[d & 255u];
-                }
-                return r;
-            };
-            const uint32_t start = draws_for(nd, true) % (uint32_t)V; nd++;
-            uint32_t nE = 1; int sp = 1;
-            if (lane == 0) { L.inE[start] = 1; L.elist[0] = (uint16_t)start; L.sv[0] = (uint16_t)start; L.se[0] = g.rowp[start]; }
+        // ---- phase 1a: start vertex, growth, move type ----
+        // getNewConnectedSet (MultiviewSegmentation.cpp:207-257) is a recursive walk with one trial per
+        // same-segment neighbour that is not yet in the set.  The trial of an undirected edge owns draw
+        // 16 + rank(edge) of the step, so the set is the component of `start` among the same-segment edges
+        // whose trial succeeds whatever the order of the walk: the four waves grow it breadth first, each
+        // wave taking frontier vertices in turn, collecting the candidate edges of 64 out-edges at a time and
+        // trying them 64 at once (the Philox call is the expensive part; candidates are ~10 % of the edges).
+        if (MODE != 2) {
+            const uint32_t start = mv_draw_at(rg, 0u) % (uint32_t)V;
             const uint16_t cs = L.cur[start];
-            while (sp) {
-                const uint32_t v = L.sv[sp - 1];
-                uint32_t e0 = L.se[sp - 1];
-                const uint32_t e1 = g.rowp[v + 1];
-                bool descended = false;
-                while (e0 < e1) {
-                    const uint32_t e = e0 + (uint32_t)lane;
-                    uint32_t j = 0;
-                    double qe = 0.0;
-                    bool cand = false;
-                    if (e < e1) { j = g.col[e]; qe = g.q[e]; cand = L.cur[j] == cs && L.inE[j] == 0; }
-                    const uint64_t m = __ballot(cand);
-                    if (m == 0) { e0 += kWave; continue; }
-                    const uint32_t dr = draws_for(nd + (uint32_t)mbcnt(m), cand);
-                    const bool ok = cand && mv_unit(dr) <= qe;
-                    const uint64_t sm = __ballot(ok);
-                    if (sm == 0) { nd += (uint32_t)__popcll((unsigned long long)m); e0 += kWave; continue; }
-                    const int first = __ffsll((unsigned long long)sm) - 1;
-                    nd += (uint32_t)__popcll((unsigned long long)(m & ((1ull << first) - 1ull))) + 1u;
-                    const uint32_t js = (uint32_t)__builtin_amdgcn_readlane((int)j, first);
-                    if (lane == 0) {
-                        L.inE[js] = 1; L.elist[nE] = (uint16_t)js;
-                        L.se[sp - 1] = e0 + (uint32_t)first + 1u;
-                        L.sv[sp] = (uint16_t)js; L.se[sp] = g.rowp[js];
-                    }
-                    wave_lds_fence();
-                    nE++; sp++;
-                    descended = true;
-                    break;
+            if (tid == 0) { L.inE[start] = 1; L.se[start] = 1u; L.elist[0] = (uint16_t)start; sh->nE = 1u; }
+            __syncthreads();
+            uint32_t* cb = L.cand + wave * 128;
+            auto try_edges = [&](uint32_t e, bool valid) {
+                if (!valid) return;
+                const uint32_t j = g.col[e];
+                if (L.inE[j]) return;
+                const double u = mv_unit(mv_draw_at(rg, 16u + g.erank[e]));
+                if (u <= g.q[e] && atomicExch(&L.se[j], 1u) == 0u) {          // inclusive (:23); first to claim j appends it
+                    const uint32_t idx = atomicAdd(&sh->nE, 1u);
+                    L.elist[idx] = (uint16_t)j; L.inE[j] = 1;
                 }
-                if (!descended) sp--;
+            };
+            uint32_t head = 0, tail = 1;
+            while (head < tail) {
+                uint32_t cn = 0;
+                for (uint32_t vi = head + (uint32_t)wave; vi < tail; vi += kMvWaves) {
+                    const uint32_t v = L.elist[vi];
+                    const uint32_t e1 = g.rowp[v + 1];
+                    for (uint32_t e0 = g.rowp[v]; e0 < e1; e0 += kWave) {
+                        const uint32_t e = e0 + (uint32_t)lane;
+                        bool cand = false;
+                        if (e < e1) { const uint32_t j = g.col[e]; cand = L.cur[j] == cs && L.inE[j] == 0; }
+                        const uint64_t m = __ballot(cand);
+                        if (m == 0) continue;
+                        if (cand) cb[cn + (uint32_t)mbcnt(m)] = e;
+                        cn += (uint32_t)__popcll((unsigned long long)m);
+                        wave_lds_fence();
+                        if (cn >= (uint32_t)kWave) {
+                            try_edges(cb[lane], true);
+                            const uint32_t rest = cn - (uint32_t)kWave;
+                            const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
+                            wave_lds_fence();
+                            if ((uint32_t)lane < rest) cb[lane] = keep;
+                            cn = rest;
+                            wave_lds_fence();
+                        }
+                    }
+                }
+                if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
+                __syncthreads();
+                head = tail; tail = sh->nE;
+                __syncthreads();
             }
-            const double moveType = mv_unit(draws_for(nd, true)); nd++;
-            if (lane == 0) {
-                sh->start = start; sh->orig = L.own[start]; sh->nE = nE; sh->nd = nd;
+            if (tid == 0) {
+                const double moveType = mv_unit(mv_draw_at(rg, 1u));
+                sh->start = start; sh->orig = L.own[start]; sh->nd = 0;
                 int kind = 0;
                 if (moveType < a.split_prob) {
                     kind = n_split >= (unsigned long long)(a.seg_cap - V) ? 3 : 1;   // max_new_segments used up
@@ -446,7 +439,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         if (kind == 3) {
             if (MODE == 2) break;                  // frozen and traced by the first half
             status = -6;
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) { L.inE[L.elist[i]] = 0; L.se[L.elist[i]] = 0u; }
             if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
             if (MODE == 1) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
             __syncthreads();
@@ -485,7 +478,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 uint32_t target = 0;
                 if (nn >= 1) {
                     // round(randbetween(0, n-1)) (PatternedMatcher.cpp:93)
-                    const double x = (double)(nn - 1) * mv_unit(mv_draw_at(rg, sh->nd));
+                    const double x = (double)(nn - 1) * mv_unit(mv_draw_at(rg, 2u));
                     const int idx = (int)(x + 0.5);
                     int seen = 0;
                     for (int b = 0; b < V; b += kWave) {
@@ -501,7 +494,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                         seen += c;
                     }
                 }
-                if (lane == 0) { sh->nn = nn; sh->target = target; if (nn >= 1) sh->nd = sh->nd + 1; else sh->kind = 2; }
+                if (lane == 0) { sh->nn = nn; sh->target = target; if (nn < 1) sh->kind = 2; }
             }
         }
         __syncthreads();
@@ -599,7 +592,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         double av = 0.0;
         if (kind != 2) {
             av = (sh->P[2] / sh->P[0]) * (sh->P[3] / sh->P[1]);
-            const double u = mv_unit(mv_draw_at(rg, sh->nd));
+            const double u = mv_unit(mv_draw_at(rg, 3u));
             if (u < av) { flags |= 1; n_accept++; }
         } else {
             n_skip++;
@@ -611,7 +604,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         }
         // clear the step's flags (the halves of a split step start from cleared LDS instead)
         if (MODE == 0) {
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) { L.inE[L.elist[i]] = 0; L.se[L.elist[i]] = 0u; }
             if (kind != 1) for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
         }
         __syncthreads();

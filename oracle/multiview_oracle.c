@@ -42,7 +42,8 @@
  *  - a segment that lost vertices in a split keeps its old plane (not refitted).
  *
  * Canonical choices where the reference is arbitrary or uses another RNG:
- * Philox4x32-10 keyed (seed, global chain id); out-edges ascending by target id
+ * Philox4x32-10 keyed (seed, global chain id), the trial of an undirected edge tied to the edge (draw
+ * 16 + rank) instead of to the order of the walk; out-edges ascending by target id
  * (boost setS out-edge lists are ordered by target); the initial Bernoulli pass
  * visits undirected edges in (i < j) lexicographic order; neighbour segments in
  * ascending id (std::set<MultiviewSegment*> of vector elements = index order);
@@ -94,9 +95,7 @@ static uint32_t mv_u32_at(const mv_rng *g, uint32_t d)
     orc_philox4x32_10(ctr, g->key, out);
     return out[(d >> 6) & 3u];
 }
-static uint32_t mv_u32(mv_rng *g) { return mv_u32_at(g, g->nd++); }
-/* MathUtils::randbetween(0,1): rand()/RAND_MAX, inclusive of 1 (MathUtils.cpp:17-20) */
-static double mv_unif(mv_rng *g) { return (double)mv_u32(g) / 4294967295.0; }
+/* MathUtils::randbetween(0,1) is rand()/RAND_MAX, inclusive of 1 (MathUtils.cpp:17-20): u32 / (2^32 - 1) */
 
 /* ---- B1 inputs: per-vertex moments, wave order over the vertex's points ---- */
 void orc_mv_vertex_moments(const float *pts /* 4 per point */, const uint32_t *pt_ptr, int V, double *out)
@@ -378,9 +377,13 @@ static uint8_t mv_step(mv_chains *c, int k, uint64_t t, double *a_out)
     uint8_t flags = 0;
     double a = 0.0;
 
-    const uint32_t start = mv_u32(&rg) % (uint32_t)V;                  /* random_vertex, :61 */
+    /* draws of a step: 0 start vertex, 1 move type, 2 target index, 3 accept; 16 + r the trial of the
+     * undirected edge of rank r (each is tried at most once per step, whichever end reaches it first) */
+    const uint32_t start = mv_u32_at(&rg, 0) % (uint32_t)V;            /* random_vertex, :61 */
     const uint32_t orig = own[start];                                   /* getParentSegment, :64 */
-    /* getNewConnectedSet: recursive DFS, one draw per same-segment unvisited neighbour (:207-257) */
+    /* getNewConnectedSet: recursive DFS, one draw per same-segment unvisited neighbour (:207-257).  The set it
+     * returns is the component of `start` among the same-segment edges whose trial succeeds, so with the
+     * trial's uniform tied to the edge the set does not depend on the order of the walk. */
     int sp = 0, nE = 1;
     inE[start] = 1; sv[0] = start; se[0] = g->rowp[start]; sp = 1;
     while (sp) {
@@ -390,9 +393,9 @@ static uint8_t mv_step(mv_chains *c, int k, uint64_t t, double *a_out)
         const uint32_t j = g->col[e];
         if (cur[v] != cur[j]) continue;
         if (inE[j]) continue;
-        if (mv_unif(&rg) <= g->q[e]) { inE[j] = 1; nE++; sv[sp] = j; se[sp] = g->rowp[j]; sp++; }
+        if ((double)mv_u32_at(&rg, 16u + c->erank[e]) / 4294967295.0 <= g->q[e]) { inE[j] = 1; nE++; sv[sp] = j; se[sp] = g->rowp[j]; sp++; }
     }
-    const double moveType = mv_unif(&rg);                               /* :76 */
+    const double moveType = (double)mv_u32_at(&rg, 1) / 4294967295.0;   /* :76 */
     uint32_t target;
     if (moveType < c->split_prob) {
         /* addNewSegment (:85-110): really moves the vertices and appends a segment */
@@ -416,7 +419,7 @@ static uint8_t mv_step(mv_chains *c, int k, uint64_t t, double *a_out)
         }
         if (nn < 1) { free(nb); flags |= 4; c->n_skip[k]++; goto hash; }   /* continue, :88-92 */
         /* round(randbetween(0, n-1)), half away from zero (:93) */
-        const double x = (double)(nn - 1) * mv_unif(&rg);
+        const double x = (double)(nn - 1) * ((double)mv_u32_at(&rg, 2) / 4294967295.0);
         int idx = (int)(x + 0.5);
         target = 0;
         for (int s = 0, seen = 0; s < c->seg_cap; ++s) if (nb[s]) { if (seen == idx) { target = (uint32_t)s; break; } seen++; }
@@ -438,7 +441,7 @@ static uint8_t mv_step(mv_chains *c, int k, uint64_t t, double *a_out)
         plane_from_moments(m, pl);
         pSB2 = set_probability(g, mem, pl, NULL);
         a = (pSB1 / pSA1) * (pSB2 / pSA2);
-        const double u = mv_unif(&rg);
+        const double u = (double)mv_u32_at(&rg, 3) / 4294967295.0;
         if (u < a) { flags |= 1; c->n_accept[k]++; }                       /* :112 */
     }
 hash:
