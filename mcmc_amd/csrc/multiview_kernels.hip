@@ -620,6 +620,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
 // (64 codes per load, chain-minor layout), and for every wanted (chain, plane) runs the same per-vertex loop
 // as the fused kernel -- the vertex's points stay in L1 / L2 for all of them.
 constexpr int kErrChainsPerBlock = 256;
+constexpr int kErrRegPts = 10;      // points per lane held in registers as doubles (640 per vertex); the rest is re-read
 __global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
 {
     const int lane = (int)threadIdx.x & 63;
@@ -627,23 +628,52 @@ __global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_
     if (v >= g.V) return;
     const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
     const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
+    const uint32_t cnt = e - b;
+    // the vertex's points, widened once: every (chain, plane) evaluation below is then arithmetic only
+    double px[kErrRegPts], py[kErrRegPts], pz[kErrRegPts];
+#pragma unroll
+    for (int j = 0; j < kErrRegPts; ++j) {
+        const uint32_t i = (uint32_t)(j * kWave + lane);
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < cnt) p = g.pts[b + i];
+        px[j] = (double)p.x; py[j] = (double)p.y; pz[j] = (double)p.z;
+    }
+    const double dn = (double)cnt;
     for (int cb = c0; cb < c1; cb += kWave) {
         const int cc = cb + lane;
         const uint32_t code = cc < c1 ? (uint32_t)x.need[(size_t)v * n_chains + cc] : 0u;
-        uint64_t m = __ballot(code != 0u);
-        while (m) {
-            const int l = __ffsll((unsigned long long)m) - 1;
-            m &= m - 1ull;
-            const int chain = cb + l;
-            const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)code, l);
-            const MvShared* sh = x.sh + chain;
-            double* out = x.err + (size_t)chain * 4 * g.V;
+        if (!__ballot(code != 0u)) continue;
+        const MvShared* shc = x.sh + (cc < c1 ? cc : c0);
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const bool want = ((code >> k) & 1u) != 0u;
+            uint64_t m = __ballot(want);
+            if (!m) continue;
+            // every lane fetches the plane of its own chain; the evaluations below broadcast them lane by lane
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0, res = 0.0;
+            if (want) { q0 = shc->pl[k][0]; q1 = shc->pl[k][1]; q2 = shc->pl[k][2]; q3 = shc->pl[k][3]; }
+            while (m) {
+                const int l = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1ull;
+                const double nx = readlane_f64(q0, l), ny = readlane_f64(q1, l), nz = readlane_f64(q2, l), d0 = readlane_f64(q3, l);
+                // same order as vertex_error: lane-local sum over i = lane, lane + 64, ..., then the wave sum
+                double part = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!((cd >> k) & 1u)) continue;
-                const double r = vertex_error(g.pts, b, e, sh->pl[k], lane);
-                if (lane == 0) out[(size_t)k * g.V + v] = r;
+                for (int j = 0; j < kErrRegPts; ++j) {
+                    if ((uint32_t)(j * kWave + lane) < cnt) {
+                        const double d = (((nx * px[j]) + (ny * py[j])) + (nz * pz[j])) + d0;
+                        part += d < 0.0 ? -d : d;
+                    }
+                }
+                for (uint32_t i = b + (uint32_t)(kErrRegPts * kWave + lane); i < e; i += kWave) {
+                    const float4 p = g.pts[i];
+                    const double d = (((nx * (double)p.x) + (ny * (double)p.y)) + (nz * (double)p.z)) + d0;
+                    part += d < 0.0 ? -d : d;
+                }
+                const double r = wave_sum_f64(part) / dn;
+                if (lane == l) res = r;
             }
+            if (want) x.err[(size_t)cc * 4 * g.V + (size_t)k * g.V + v] = res;
         }
     }
 }
