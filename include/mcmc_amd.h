@@ -275,6 +275,11 @@ int mcmc_mv_chains_get_scalars(mcmc_mv *mv, uint64_t *n_accept, uint64_t *n_spli
                                uint64_t *trace_hash, int32_t *n_segments, int32_t *status);
 int mcmc_mv_chains_get_planes(mcmc_mv *mv, int chain, double *out /* n_segments*5 */);
 /* Device time of the last mcmc_mv_chains_run launch, milliseconds (< 0: none). */
+/* Diagnostic (no counterpart in the reference): with option "profile" = 1 the first half of a split
+ * iteration sums shader-clock cycles per phase over all chains of the last run: [0] set-up, [1] start vertex,
+ * [2] growth, [3] move type / neighbour segments, [4] planes, [5] hand-over, [6] write-back, [8] growth levels,
+ * [9] grown vertices. */
+int mcmc_mv_chains_get_profile(mcmc_mv *mv, uint64_t *out16);
 double mcmc_mv_last_run_ms(mcmc_mv *mv);
 
 #ifdef __cplusplus

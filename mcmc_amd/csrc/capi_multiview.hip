@@ -31,6 +31,8 @@ struct mcmc_mv {
     // split step: exchange buffers between the two halves of an iteration and the error kernel
     void* ex_sh = nullptr; uint8_t *ex_inE = nullptr, *ex_need = nullptr; double* ex_err = nullptr;
     int opt_split = -1;   // -1 automatic (split from 32 chains on), 0 fused, 1 split
+    int opt_prof = 0;
+    unsigned long long* d_prof = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
 };
 
@@ -64,7 +66,7 @@ void free_chains(mcmc_mv* c)
     mvfree(c->status); mvfree(c->n_accept); mvfree(c->n_split); mvfree(c->n_skip); mvfree(c->trace_hash);
     mvfree(c->trace); mvfree(c->trace_a);
     { uint8_t* p = static_cast<uint8_t*>(c->ex_sh); mvfree(p); c->ex_sh = nullptr; }
-    mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err);
+    mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err); mvfree(c->d_prof);
     c->n = 0; c->trace_cap = 0; c->last_steps = 0;
 }
 MvGraph graph_of(const mcmc_mv* c)
@@ -325,6 +327,7 @@ int mcmc_mv_set_option(mcmc_mv* c, const char* name, int value)
 {
     if (!c || !name) return MCMC_E_BADARG;
     if (std::string(name) == "split_step") c->opt_split = value;
+    else if (std::string(name) == "profile") c->opt_prof = value;
     else return mfail(c, MCMC_E_BADARG, std::string("mv_set_option: unknown option ") + name);
     return MCMC_OK;
 }
@@ -358,12 +361,26 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         MVCHK(c, mvalloc(&shp, N * mv_exchange_shared_bytes())); c->ex_sh = shp;
         MVCHK(c, mvalloc(&c->ex_inE, NV)); MVCHK(c, mvalloc(&c->ex_need, NV)); MVCHK(c, mvalloc(&c->ex_err, NV * 4));
     }
+    if (c->opt_prof) {
+        if (!c->d_prof) MVCHK(c, mvalloc(&c->d_prof, 16));
+        MVCHK(c, hipMemsetAsync(c->d_prof, 0, 16 * 8, c->stream));
+        a.prof = c->d_prof;
+    }
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
     if (split) MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->stream));
     else MVCHK(c, launch_mv_chain_run(graph_of(c), a, c->stream));
     MVCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     c->step += steps; c->last_steps = steps;
+    return MCMC_OK;
+}
+
+int mcmc_mv_chains_get_profile(mcmc_mv* c, uint64_t* out16)
+{
+    if (!c || !out16 || !c->d_prof) return mfail(c, MCMC_E_STATE, "mv_chains_get_profile: set option profile and run first");
+    MVCHK(c, hipSetDevice(c->device));
+    MVCHK(c, hipMemcpyAsync(out16, c->d_prof, 16 * 8, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipStreamSynchronize(c->stream));
     return MCMC_OK;
 }
 

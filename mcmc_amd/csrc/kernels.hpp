@@ -121,6 +121,7 @@ struct MvChainArgs {
     unsigned long long *n_accept, *n_split, *n_skip, *trace_hash;
     uint8_t* trace; double* trace_a;   // optional [C][trace_stride], this launch writes from trace_first on
     unsigned long long trace_stride, trace_first;
+    unsigned long long* prof;  // optional [16]: shader-clock cycles per phase of the first half, summed over chains
 };
 
 hipError_t launch_mv_vertex_moments(const MvGraph& g, double* out, hipStream_t st);

@@ -138,12 +138,27 @@ MC_D int pool_moments(const double* vm, int V, int lane, Pred pred, double* m)
 #pragma unroll
     for (int k = 0; k < 10; ++k) a[k] = 0.0;
     int n = 0;
-    for (int v = lane; v < V; v += kWave) {
-        if (!pred(v)) continue;
-        n++;
-        const double* r = vm + (size_t)v * 10;
+    // two rows per trip, fetched whether or not they are members (the table is L2-resident): the loads of a
+    // trip then do not wait for the membership test, and only members are added, in vertex order
+    for (int v0 = lane; v0 < V; v0 += 2 * kWave) {
+        const int v1 = v0 + kWave;
+        const bool in0 = pred(v0), in1 = v1 < V && pred(v1);
+        if (!__ballot(in0 || in1)) continue;
+        const double* r0 = vm + (size_t)v0 * 10;
+        const double* r1 = vm + (size_t)(v1 < V ? v1 : v0) * 10;
+        double t0[10], t1[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) a[k] += r[k];
+        for (int k = 0; k < 10; ++k) { t0[k] = r0[k]; t1[k] = r1[k]; }
+        if (in0) {
+            n++;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[k] += t0[k];
+        }
+        if (in1) {
+            n++;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[k] += t1[k];
+        }
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) m[k] = wave_sum_f64(a[k]);
@@ -358,7 +373,16 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     int nseg = a.nseg[chain], status = a.status[chain];
     unsigned long long n_accept = a.n_accept[chain], n_split = a.n_split[chain], n_skip = a.n_skip[chain];
     unsigned long long trace_hash = a.trace_hash[chain];
+    unsigned long long ptime = (MODE == 1 && a.prof) ? __builtin_readcyclecounter() : 0ull;
+    auto stamp = [&](int k) {
+        if (MODE == 1 && a.prof && tid == 0) {
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            atomicAdd(a.prof + k, t1 - ptime);
+            ptime = t1;
+        }
+    };
     __syncthreads();
+    stamp(0);
 
     for (unsigned long long ts = 0; ts < a.steps; ++ts) {
         const unsigned long long t = a.step0 + ts;
@@ -392,36 +416,61 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 }
             };
             uint32_t head = 0, tail = 1;
+            stamp(1);
             while (head < tail) {
+                if (MODE == 1 && a.prof && tid == 0) atomicAdd(a.prof + 8, 1ull);
                 uint32_t cn = 0;
-                for (uint32_t vi = head + (uint32_t)wave; vi < tail; vi += kMvWaves) {
-                    const uint32_t v = L.elist[vi];
-                    const uint32_t e1 = g.rowp[v + 1];
-                    for (uint32_t e0 = g.rowp[v]; e0 < e1; e0 += kWave) {
-                        const uint32_t e = e0 + (uint32_t)lane;
-                        bool cand = false;
-                        if (e < e1) { const uint32_t j = g.col[e]; cand = L.cur[j] == cs && L.inE[j] == 0; }
-                        const uint64_t m = __ballot(cand);
-                        if (m == 0) continue;
-                        if (cand) cb[cn + (uint32_t)mbcnt(m)] = e;
-                        cn += (uint32_t)__popcll((unsigned long long)m);
-                        wave_lds_fence();
-                        if (cn >= (uint32_t)kWave) {
-                            try_edges(cb[lane], true);
-                            const uint32_t rest = cn - (uint32_t)kWave;
-                            const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
+                // a wave's frontier vertices in turn; the CSR bounds of the next one are fetched under the
+                // scan of the current one, and up to 256 of its out-edges are loaded before any is looked at
+                uint32_t vi = head + (uint32_t)wave, r0 = 0, e1 = 0;
+                if (vi < tail) { const uint32_t v = L.elist[vi]; r0 = g.rowp[v]; e1 = g.rowp[v + 1]; }
+                while (vi < tail) {
+                    const uint32_t vn = vi + (uint32_t)kMvWaves;
+                    uint32_t nr0 = 0, ne1 = 0;
+                    if (vn < tail) { const uint32_t v = L.elist[vn]; nr0 = g.rowp[v]; ne1 = g.rowp[v + 1]; }
+                    for (uint32_t eb = r0; eb < e1; eb += 4u * kWave) {
+                        uint32_t jj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t e = eb + (uint32_t)(u * kWave + lane);
+                            jj[u] = e < e1 ? g.col[e] : 0xFFFFFFFFu;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t e0 = eb + (uint32_t)(u * kWave);
+                            if (e0 >= e1) break;
+                            const uint32_t e = e0 + (uint32_t)lane;
+                            bool cand = false;
+                            if (jj[u] != 0xFFFFFFFFu) {
+                                const uint16_t sj = L.cur[jj[u]];
+                                if (sj == cs) cand = L.inE[jj[u]] == 0;
+                                else L.nb[sj] = 1;      // getNeighborSegments (MultiviewSegmentation.cpp:112-142), same scan
+                            }
+                            const uint64_t m = __ballot(cand);
+                            if (m == 0) continue;
+                            if (cand) cb[cn + (uint32_t)mbcnt(m)] = e;
+                            cn += (uint32_t)__popcll((unsigned long long)m);
                             wave_lds_fence();
-                            if ((uint32_t)lane < rest) cb[lane] = keep;
-                            cn = rest;
-                            wave_lds_fence();
+                            if (cn >= (uint32_t)kWave) {
+                                try_edges(cb[lane], true);
+                                const uint32_t rest = cn - (uint32_t)kWave;
+                                const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
+                                wave_lds_fence();
+                                if ((uint32_t)lane < rest) cb[lane] = keep;
+                                cn = rest;
+                                wave_lds_fence();
+                            }
                         }
                     }
+                    vi = vn; r0 = nr0; e1 = ne1;
                 }
                 if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
                 __syncthreads();
                 head = tail; tail = sh->nE;
                 __syncthreads();
             }
+            stamp(2);
+            if (MODE == 1 && a.prof && tid == 0) atomicAdd(a.prof + 9, (unsigned long long)sh->nE);
             if (tid == 0) {
                 const double moveType = mv_unit(mv_draw_at(rg, 1u));
                 sh->start = start; sh->orig = L.own[start]; sh->nd = 0;
@@ -458,17 +507,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             if (tid == 0) pvalid[tg] = 0;
             nseg++; n_split++;
         } else {
-            // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids
-            const uint16_t cs = L.cur[sh->start];
-            for (uint32_t i = (uint32_t)wave; i < nE; i += kMvWaves) {
-                const uint32_t v = L.elist[i];
-                const uint32_t e1 = g.rowp[v + 1];
-                for (uint32_t e = g.rowp[v] + (uint32_t)lane; e < e1; e += kWave) {
-                    const uint16_t sj = L.cur[g.col[e]];
-                    if (sj != cs) L.nb[sj] = 1;
-                }
-            }
-            __syncthreads();
+            // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids: marked by the growth scan,
+            // which visits every out-edge of every grown vertex once
             if (wave == 0) {
                 int nn = 0;
                 for (int b = 0; b < V; b += kWave) {
@@ -498,6 +538,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             }
         }
         __syncthreads();
+        stamp(3);
         kind = sh->kind;
         const uint32_t target = sh->target;
         if (kind != 2) {
@@ -539,6 +580,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 }
             }
             __syncthreads();
+            stamp(4);
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
             if (MODE == 1) {
@@ -585,6 +627,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
             uint32_t* dst = reinterpret_cast<uint32_t*>(x.sh + chain);
             for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += kMvThreads) dst[k] = src[k];
+            stamp(5);
             continue;
         }
         // ---- phase 5: computeProposalRatio + accept (MultiviewSegmentation.cpp:270-274; PatternedMatcher.cpp:111-112) ----
@@ -605,11 +648,12 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         // clear the step's flags (the halves of a split step start from cleared LDS instead)
         if (MODE == 0) {
             for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) { L.inE[L.elist[i]] = 0; L.se[L.elist[i]] = 0u; }
-            if (kind != 1) for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
+            for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
         }
         __syncthreads();
     }
     if (MODE != 2) for (int v = tid; v < V; v += kMvThreads) gown[v] = L.own[v];
+    stamp(6);
     if (tid == 0) {
         if (MODE != 2) { a.nseg[chain] = nseg; a.status[chain] = status; a.n_split[chain] = n_split; }
         if (MODE != 1) { a.n_accept[chain] = n_accept; a.n_skip[chain] = n_skip; a.trace_hash[chain] = trace_hash; }

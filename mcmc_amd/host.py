@@ -113,6 +113,7 @@ def load():
         "mcmc_mv_chains_get_labels": (i, [vp, i, vp]),
         "mcmc_mv_chains_get_scalars": (i, [vp] + [vp] * 6),
         "mcmc_mv_chains_get_planes": (i, [vp, i, vp]),
+        "mcmc_mv_chains_get_profile": (i, [vp, vp]),
         "mcmc_mv_last_run_ms": (dbl, [vp]),
         "mcmc_overseg_default_params": (None, [C.POINTER(OversegParams)]),
         "mcmc_overseg_create": (i, [i, i, i, C.POINTER(vp)]),
@@ -434,6 +435,11 @@ class Multiview:
     def planes(self, chain, n_segments):
         out = np.zeros((n_segments, 5))
         self._ck(self.L.mcmc_mv_chains_get_planes(self.h, chain, _ptr(out, np.float64)))
+        return out
+
+    def profile(self):
+        out = np.zeros(16, np.uint64)
+        self._ck(self.L.mcmc_mv_chains_get_profile(self.h, _ptr(out, np.uint64)))
         return out
 
     def last_run_ms(self):

@@ -11,5 +11,14 @@ if os.environ.get("FUSED"):
     m.set_option("split_step", 0)
 m.chains_init(int(os.environ.get("CHAINS", 1024)), seed=1)
 m.chains_run(2)
+if os.environ.get("PHASES"):
+    m.set_option("profile", 1)
 m.chains_run(int(os.environ.get("STEPS", 10)))
 print("ms per launch", m.last_run_ms())
+if os.environ.get("PHASES"):
+    p = m.profile().astype(float)
+    n = float(os.environ.get("CHAINS", 1024)) * float(os.environ.get("STEPS", 10))
+    names = ["set-up", "start", "growth", "move/neighbours", "planes", "hand-over", "write-back"]
+    for k, nm in enumerate(names):
+        print(f"{nm:16s} {p[k] / n:10.0f} cycles per chain-step")
+    print(f"levels {p[8] / n:.1f}  grown vertices {p[9] / n:.1f}")
