@@ -190,7 +190,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # MCMC_BENCH_FORCE_DIST=1: rehearse the RCCL path with a single rank (one-GPU boxes)
+    if world > 1 or os.environ.get("MCMC_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
