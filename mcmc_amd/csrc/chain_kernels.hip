@@ -820,12 +820,13 @@ static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size
     if constexpr (!PROF && WPB == 4 && TAB) {
         if (a.prof) return launch_variant<4, true, true>(a, s_lds, e2_lds, bytes, st);
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce once;
+    bool* attr_done = once.slot();
+    if (!attr_done || !*attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, PROF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        if (attr_done) *attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
     hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);

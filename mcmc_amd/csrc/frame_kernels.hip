@@ -912,15 +912,16 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
     // mode 0: LDS table + log, 1: log only (HBM atomics per record), 2: generic (any width)
     dim3 grid(a.bands, n_frames);
     if (mode == 3 || mode == 4) {
-        static bool attr3 = false;
-        if (!attr3) {
+        static DeviceOnce once3;
+        bool* attr3 = once3.slot();
+        if (!attr3 || !*attr3) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
             if (e != hipSuccess) return e;
-            attr3 = true;
+            if (attr3) *attr3 = true;
         }
         // ragged: some strip has fewer rows than the others
         const int rpb = (a.H + a.bands - 1) / a.bands, nsub = threads / (a.W / 8);
@@ -937,12 +938,13 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
     if (mode == 2) {
         hipLaunchKernelGGL(sp_moments_generic_kernel, grid, dim3(256), 0, st, a);
     } else if (mode == 0) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static DeviceOnce once0;
+        bool* attr_done = once0.slot();
+        if (!attr_done || !*attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_done = true;
+            if (attr_done) *attr_done = true;
         }
         hipLaunchKernelGGL(sp_moments_kernel<true>, grid, dim3(threads), lds_bytes, st, a);
     } else {

@@ -5,6 +5,19 @@
 
 namespace mc {
 
+// hipFuncSetAttribute is a property of a function on ONE device: a flag per (call site, device).  Setting it
+// twice is harmless, so two host threads racing on the first launch need no lock.
+struct DeviceOnce {
+    bool done[64] = {};
+    bool* slot()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+        return &done[d];
+    }
+};
+
+
 // per-chain segment cache row (f64): 10 exact sums, sum of ssr, probabilityL, member count, pad
 constexpr int kSegCacheStride = 16, kSegCacheUsed = 13, kSegCacheP = 11, kSegCacheN = 12;
 

@@ -852,8 +852,9 @@ size_t mv_chain_lds_bytes(int V) { return mv_lds_bytes(V, true); }
 
 static hipError_t mv_set_lds_attr()
 {
-    static bool done = false;
-    if (done) return hipSuccess;
+    static DeviceOnce once;
+    bool* done = once.slot();
+    if (done && *done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
@@ -869,7 +870,7 @@ static hipError_t mv_set_lds_attr()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_fit_segment_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
-    done = true;
+    if (done) *done = true;
     return hipSuccess;
 }
 
