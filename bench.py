@@ -171,11 +171,24 @@ def multiview_line(host, device, n_chains, steps):
     ms = m.last_run_ms()
     sc = m.scalars()
     assert (sc["status"] == 0).all()
+    # one more launch with the phase counters on (not timed): points of SB1 u SB2 per proposal -> SURVEY 8(d)'s
+    # algorithmic bytes for K4 (2 passes x 16 B per point); the chains share the points through L2 / registers,
+    # so this rate may exceed the HBM peak -- it is reported, not claimed as a roofline fraction
+    alg = None
+    if n_chains >= 32:
+        m.set_option("profile", 1)
+        m.chains_run(steps)
+        m.synchronize() if hasattr(m, "synchronize") else None
+        pts = float(m.profile()[10]) / (n_chains * steps)
+        alg = {"points_per_proposal": pts, "bytes_per_proposal": 32.0 * pts,
+               "GB_per_s": 32.0 * pts * n_chains * steps / (ms * 1e-3) / 1e9,
+               "evaluations_per_proposal": float(m.profile()[11]) / (n_chains * steps)}
     m.close()
     return {"workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
             "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,
             "accept_rate": float(sc["n_accept"].sum()) / (2.0 * n_chains * steps),
+            "algorithmic": alg,
             "bound": "f64 VALU of the L1 residual pass (evaluated for all chains vertex by vertex, points read once per "
                      "vertex block); the per-chain growth is breadth first over four waves"}
 

@@ -210,8 +210,8 @@ template <int CTRL>
 MC_D double dpp_f64(double v)
 {
     const uint64_t u = d2u(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
     return u2d(((uint64_t)hi << 32) | lo);
 }
 MC_D double readlane_f64(double v, int src)
@@ -247,19 +247,19 @@ MC_D uint64_t wave_sum_u64(uint64_t v)
 }
 MC_D int wave_sum_i32(int v)
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
     return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
            (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 MC_D int wave_min_i32(int v)
 {
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
     return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }

@@ -591,6 +591,11 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                                          ((uint32_t)(o == orig && !ie) << 2) | ((uint32_t)(o == target || ie) << 3);
                     x.need[(size_t)v * a.n_chains + chain] = (uint8_t)nb4;
                     x.inE[(size_t)chain * V + v] = L.inE[v];
+                    if (a.prof && (o == orig || o == target || ie)) {
+                        // points of SB1 u SB2 (the algorithmic-bytes figure of SURVEY 8d) and evaluations asked for
+                        atomicAdd(a.prof + 10, (unsigned long long)(g.pt_ptr[v + 1] - g.pt_ptr[v]));
+                        atomicAdd(a.prof + 11, (unsigned long long)__popc(nb4));
+                    }
                 }
             }
             if (MODE == 0)
@@ -663,26 +668,19 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
 // L1 residuals of one split step: wave = (vertex, block of chains).  The wave reads which chains want the vertex
 // (64 codes per load, chain-minor layout), and for every wanted (chain, plane) runs the same per-vertex loop
 // as the fused kernel -- the vertex's points stay in L1 / L2 for all of them.
-constexpr int kErrChainsPerBlock = 256;
+constexpr int kErrChainsPerBlock = 64;   // one wave = (vertex, 64 chains): fine-grained, the need for a vertex is very uneven
 constexpr int kErrRegPts = 10;      // points per lane held in registers as doubles (640 per vertex); the rest is re-read
-__global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
+// The evaluations of one wave for NF full rows of 64 points in registers (+ one partial row, + the points past
+// the registers): straight-line arithmetic per evaluation, so the rows' products overlap and only the NF adds
+// into `part` are a chain.  |d| as fabs: it differs from `d < 0 ? -d : d` only in the sign of a zero or a NaN,
+// neither of which changes `part` as a value (a NaN residual ends as probability 0, MultiviewSegment.cpp:86-91).
+template <int NF>
+MC_D void err_block(const MvGraph& g, int n_chains, const MvExchange& x, int v, int c0, int c1, uint32_t b, uint32_t e,
+                    const double (&px)[kErrRegPts], const double (&py)[kErrRegPts], const double (&pz)[kErrRegPts], int lane)
 {
-    const int lane = (int)threadIdx.x & 63;
-    const int v = (int)(blockIdx.x * kMvWaves + (threadIdx.x >> 6));
-    if (v >= g.V) return;
-    const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
-    const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
     const uint32_t cnt = e - b;
-    // the vertex's points, widened once: every (chain, plane) evaluation below is then arithmetic only
-    double px[kErrRegPts], py[kErrRegPts], pz[kErrRegPts];
-#pragma unroll
-    for (int j = 0; j < kErrRegPts; ++j) {
-        const uint32_t i = (uint32_t)(j * kWave + lane);
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < cnt) p = g.pts[b + i];
-        px[j] = (double)p.x; py[j] = (double)p.y; pz[j] = (double)p.z;
-    }
     const double dn = (double)cnt;
+    const bool tail = NF < kErrRegPts && (uint32_t)(NF * kWave + lane) < cnt;
     for (int cb = c0; cb < c1; cb += kWave) {
         const int cc = cb + lane;
         const uint32_t code = cc < c1 ? (uint32_t)x.need[(size_t)v * n_chains + cc] : 0u;
@@ -703,22 +701,61 @@ __global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_
                 // same order as vertex_error: lane-local sum over i = lane, lane + 64, ..., then the wave sum
                 double part = 0.0;
 #pragma unroll
-                for (int j = 0; j < kErrRegPts; ++j) {
-                    if ((uint32_t)(j * kWave + lane) < cnt) {
-                        const double d = (((nx * px[j]) + (ny * py[j])) + (nz * pz[j])) + d0;
-                        part += d < 0.0 ? -d : d;
+                for (int j = 0; j < NF; ++j) {
+                    const double d = (((nx * px[j]) + (ny * py[j])) + (nz * pz[j])) + d0;
+                    part += __builtin_fabs(d);
+                }
+                if (NF < kErrRegPts) {
+                    constexpr int J = NF < kErrRegPts ? NF : 0;
+                    const double d = (((nx * px[J]) + (ny * py[J])) + (nz * pz[J])) + d0;
+                    part += tail ? __builtin_fabs(d) : 0.0;
+                } else {
+                    for (uint32_t i = b + (uint32_t)(kErrRegPts * kWave + lane); i < e; i += kWave) {
+                        const float4 p = g.pts[i];
+                        const double d = (((nx * (double)p.x) + (ny * (double)p.y)) + (nz * (double)p.z)) + d0;
+                        part += __builtin_fabs(d);
                     }
                 }
-                for (uint32_t i = b + (uint32_t)(kErrRegPts * kWave + lane); i < e; i += kWave) {
-                    const float4 p = g.pts[i];
-                    const double d = (((nx * (double)p.x) + (ny * (double)p.y)) + (nz * (double)p.z)) + d0;
-                    part += d < 0.0 ? -d : d;
-                }
-                const double r = wave_sum_f64(part) / dn;
+                const double r = wave_sum_f64(part);
                 if (lane == l) res = r;
             }
-            if (want) x.err[(size_t)cc * 4 * g.V + (size_t)k * g.V + v] = res;
+            // the mean: one division per lane for its own chain instead of one per evaluation
+            if (want) x.err[(size_t)cc * 4 * g.V + (size_t)k * g.V + v] = res / dn;
         }
+    }
+}
+
+__global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int v = (int)(blockIdx.x * kMvWaves + (threadIdx.x >> 6));
+    if (v >= g.V) return;
+    const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
+    {   // nothing wanted from this vertex by these chains: leave before touching its points
+        bool any = false;
+        for (int cb = c0; cb < c1; cb += kWave) {
+            const int cc = cb + lane;
+            any = any || (cc < c1 && x.need[(size_t)v * n_chains + cc] != 0);
+        }
+        if (!__ballot(any)) return;
+    }
+    const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
+    const uint32_t cnt = e - b;
+    // the vertex's points, widened once: every (chain, plane) evaluation is then arithmetic only
+    double px[kErrRegPts], py[kErrRegPts], pz[kErrRegPts];
+#pragma unroll
+    for (int j = 0; j < kErrRegPts; ++j) {
+        const uint32_t i = (uint32_t)(j * kWave + lane);
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < cnt) p = g.pts[b + i];
+        px[j] = (double)p.x; py[j] = (double)p.y; pz[j] = (double)p.z;
+    }
+    switch (cnt / (uint32_t)kWave) {
+#define MV_ERR_CASE(N) case N: err_block<N>(g, n_chains, x, v, c0, c1, b, e, px, py, pz, lane); break
+        MV_ERR_CASE(0); MV_ERR_CASE(1); MV_ERR_CASE(2); MV_ERR_CASE(3); MV_ERR_CASE(4);
+        MV_ERR_CASE(5); MV_ERR_CASE(6); MV_ERR_CASE(7); MV_ERR_CASE(8); MV_ERR_CASE(9);
+#undef MV_ERR_CASE
+        default: err_block<kErrRegPts>(g, n_chains, x, v, c0, c1, b, e, px, py, pz, lane); break;
     }
 }
 
@@ -917,6 +954,7 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, vo
     if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
     MvExchange x{ reinterpret_cast<MvShared*>(ex_sh), ex_inE, ex_need, ex_err };
     const dim3 egrid((unsigned)((g.V + kMvWaves - 1) / kMvWaves), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
+    if (egrid.y > 65535u) return hipErrorInvalidValue;      // > 4 M chains per launch: shard the chains
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
