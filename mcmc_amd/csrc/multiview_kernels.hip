@@ -281,38 +281,68 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
     MvLds L = mv_carve(smem, V, false);
     const int chain = (int)blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int v = tid; v < V; v += kMvThreads) L.cur[v] = 0xFFFFu;
+    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = 0xFFFFu; L.se[v] = 0u; }
     __syncthreads();
-    if (wave == 0) {
-        // Bernoulli(q) per undirected edge (draw index = rank of the edge, so both directions agree), then
-        // connected components numbered by their smallest vertex.  One wave: 64 out-edges of the popped
-        // vertex per pass; every on-edge to an unlabelled vertex labels and pushes it.
+    {
+        // Bernoulli(q) per undirected edge (draw index = rank of the edge, so both directions agree and the
+        // order of the search does not matter), then connected components numbered by their smallest vertex.
+        // A component is grown breadth first by the four waves, as in the chain step: a wave takes frontier
+        // vertices in turn, collects the out-edges to unlabelled vertices and tries them 64 at a time; a
+        // vertex is claimed with atomicExch on its claim word.
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, 0xFFFFFFFFu, 0xFFFFFFFFu };
+        uint32_t* cb = L.cand + wave * 128;
         int ncomp = 0;
         for (int s0 = 0; s0 < V; ++s0) {
-            if (L.cur[s0] != 0xFFFFu) continue;      // wave-uniform (LDS value)
-            int sp = 1;
-            if (lane == 0) { L.sv[0] = (uint16_t)s0; L.cur[s0] = (uint16_t)ncomp; }
-            while (sp) {
-                const int v = L.sv[sp - 1];
-                sp--;
-                const uint32_t e1 = g.rowp[v + 1];
-                for (uint32_t eb = g.rowp[v]; eb < e1; eb += kWave) {
-                    const uint32_t e = eb + (uint32_t)lane;
-                    bool ok = false;
-                    uint32_t j = 0;
-                    if (e < e1) {
-                        j = g.col[e];
-                        if (L.cur[j] == 0xFFFFu) ok = mv_unit(mv_draw_at(rg, g.erank[e])) <= g.q[e];   // inclusive (:23)
-                    }
-                    const uint64_t m = __ballot(ok);
-                    if (ok) { L.cur[j] = (uint16_t)ncomp; L.sv[sp + mbcnt(m)] = (uint16_t)j; }
-                    sp += __popcll((unsigned long long)m);
+            if (L.cur[s0] != 0xFFFFu) continue;      // uniform over the workgroup (LDS value, read after a barrier)
+            __syncthreads();                          // every wave has read cur[s0] before it is written
+            if (tid == 0) { L.cur[s0] = (uint16_t)ncomp; L.se[s0] = 1u; L.elist[0] = (uint16_t)s0; L.sh->nE = 1u; }
+            __syncthreads();
+            auto try_edges = [&](uint32_t e, bool valid) {
+                if (!valid) return;
+                const uint32_t j = g.col[e];
+                if (L.cur[j] != 0xFFFFu) return;
+                const uint32_t er = g.erank[e];
+                const double qe = g.q[e];
+                if (mv_unit(mv_draw_at(rg, er)) <= qe && atomicExch(&L.se[j], 1u) == 0u) {   // inclusive (:23)
+                    const uint32_t idx = atomicAdd(&L.sh->nE, 1u);
+                    L.elist[idx] = (uint16_t)j; L.cur[j] = (uint16_t)ncomp;
                 }
+            };
+            uint32_t head = 0, tail = 1;
+            while (head < tail) {
+                uint32_t cn = 0;
+                for (uint32_t vi = head + (uint32_t)wave; vi < tail; vi += kMvWaves) {
+                    const uint32_t v = L.elist[vi];
+                    const uint32_t e1 = g.rowp[v + 1];
+                    for (uint32_t e0 = g.rowp[v]; e0 < e1; e0 += kWave) {
+                        const uint32_t e = e0 + (uint32_t)lane;
+                        uint32_t j = 0;
+                        bool cand = false;
+                        if (e < e1) { j = g.col[e]; cand = L.cur[j] == 0xFFFFu; }
+                        const uint64_t m = __ballot(cand);
+                        if (m == 0) continue;
+                        if (cand) cb[cn + (uint32_t)mbcnt(m)] = e;
+                        cn += (uint32_t)__popcll((unsigned long long)m);
+                        wave_lds_fence();
+                        if (cn >= (uint32_t)kWave) {
+                            try_edges(cb[lane], true);
+                            const uint32_t rest = cn - (uint32_t)kWave;
+                            const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
+                            wave_lds_fence();
+                            if ((uint32_t)lane < rest) cb[lane] = keep;
+                            cn = rest;
+                            wave_lds_fence();
+                        }
+                    }
+                }
+                if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
+                __syncthreads();
+                head = tail; tail = L.sh->nE;
+                __syncthreads();
             }
             ncomp++;
         }
-        if (lane == 0) L.sh->nn = ncomp;
+        if (tid == 0) L.sh->nn = ncomp;
     }
     __syncthreads();
     const int nseg = L.sh->nn;

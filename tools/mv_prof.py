@@ -15,6 +15,7 @@ if os.environ.get("PHASES"):
     m.set_option("profile", 1)
 m.chains_run(int(os.environ.get("STEPS", 10)))
 print("ms per launch", m.last_run_ms())
+print("segments per chain (mean)", float(m.scalars()["n_segments"].mean()))
 if os.environ.get("PHASES"):
     p = m.profile().astype(float)
     n = float(os.environ.get("CHAINS", 1024)) * float(os.environ.get("STEPS", 10))
