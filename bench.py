@@ -88,6 +88,24 @@ def cpu_baseline(sc, seed, seconds):
                       f"oracle/mcmc_oracle.c -O2 -ffp-contract=off, 1 thread, {cpu}"}
 
 
+def same_computation_check(sc, seed, total_steps, gpu_scalars, n=4):
+    """show that the CPU baseline and the GPU run are the same computation.  The first `n` chains of
+    the GPU job are re-run on the oracle with the same key and step count; the hash of the accept/case trace,
+    the state hash and the energy bits must be identical.  Part of the cpu_baseline leg (not timed)."""
+    from tests import oracle_lib as O
+    S = sc.n_superpixels
+    fit, valid, _ = O.local_fit(O.moments(sc.disp, sc.label, S), sc.width, sc.height)
+    _, q = O.edge_probs(fit, valid, sc.row_ptr, sc.col)
+    ch = O.Chains(fit, valid, sc.row_ptr, sc.col, q, n, seed, chain_offset=0)
+    ch.run(0, total_steps)
+    o = ch.scalars()
+    ok = all(np.array_equal(np.asarray(gpu_scalars[k][:n]).view(np.uint64) if k == "energy" else gpu_scalars[k][:n],
+                            np.asarray(o[k]).view(np.uint64) if k == "energy" else o[k])
+             for k in ("trace_hash", "state_hash", "energy", "n_accept"))
+    return {"chains": n, "steps_per_chain": int(total_steps), "identical_to_gpu": bool(ok),
+            "trace_hash_chain0": "%016x" % int(o["trace_hash"][0])}
+
+
 def cpu_baseline_all_cores(sc, seed, seconds, threads):
     """The same oracle, chains spread over host threads (ctypes releases the GIL): what SURVEY section 8d
     asks for beside the single-threaded figure.  Each thread owns its chains; proposals / wall time."""
@@ -293,6 +311,8 @@ def main():
             out["roofline"] = k1_roofline(host, scs, a.roofline_frames, a.roofline_reps, local)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, a.seed, a.cpu_seconds)
+            out["cpu_baseline"]["same_computation"] = same_computation_check(sc, a.seed, total_steps, sca)
+            assert out["cpu_baseline"]["same_computation"]["identical_to_gpu"], "GPU chains differ from the oracle"
             nthr = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(sc, a.seed, min(a.cpu_seconds, 6.0), min(nthr, 16))
     if rank == 0:
