@@ -144,7 +144,8 @@ int mcmc_chains_recompute_energy(mcmc_ctx *ctx, double *out /* n_chains */);
 double mcmc_last_kernel_ms(mcmc_ctx *ctx, int kernel);
 int mcmc_set_timing(mcmc_ctx *ctx, int enable);
 /* Launch-shape overrides for tuning runs (0 / -1 = automatic): "k1_bands",
- * "k1_threads", "k1_use_lds", "k1_debug", "k3_profile".  Results never depend on them (integer sums). */
+ * "k1_threads", "k1_use_lds", "k1_debug", "k3_profile", "k3_dense" (eight chains per workgroup with the records
+ * read through L2: -1 never, 0 when the chains exceed four per CU, 1 always).  Results never depend on them. */
 int mcmc_ctx_set_option(mcmc_ctx *ctx, const char *name, int value);
 /* After option "k3_profile" = 1 and a run: shader-clock cycles summed over chains for 12
  * phases of the step, then sums of component size, draws and refit members (diagnostic build of the chain kernel; never used for reported numbers). */

@@ -64,7 +64,7 @@ struct mcmc_ctx {
     bool ev_valid[K_COUNT]{};
     int chain_variant = 0;
     // tuning overrides (0 / -1 = automatic)
-    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k1_version = 0;
+    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k1_version = 0, opt_k3_dense = 0;
     unsigned long long* d_prof = nullptr;
 };
 
@@ -227,6 +227,7 @@ int mcmc_ctx_set_option(mcmc_ctx* c, const char* name, int value)
     else if (n == "k1_use_lds") c->opt_k1_lds = value;
     else if (n == "k1_debug") c->opt_k1_debug = value;
     else if (n == "k3_profile") c->opt_k3_prof = value;
+    else if (n == "k3_dense") c->opt_k3_dense = value;
     else if (n == "k1_version") c->opt_k1_version = value;
     else return fail(c, MCMC_E_BADARG, "set_option: unknown option " + n);
     return MCMC_OK;
@@ -541,6 +542,7 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
         HIPCHK(c, hipMemsetAsync(c->d_prof, 0, 16 * 8, c->stream));
         a.prof = c->d_prof;
     }
+    a.dense_variant = c->opt_k3_dense;
     int s_used = 0, e_used = 0;
     const int frames_needed = (h.n + h.cpf - 1) / h.cpf;
     for (int f = 0; f < frames_needed; ++f) { s_used = std::max(s_used, c->h_S[f]); e_used = std::max(e_used, (int)c->h_E2[f]); }

@@ -159,12 +159,13 @@ __host__ __device__ inline size_t queue_slots(int S, int E2) { return (size_t)S 
 
 // The FIFO lives in LDS next to the tables; frames whose tables do not fit keep it in HBM too (a.slots_g), which
 // leaves room for several chains per workgroup.
-__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds)
+// rec_lds: the per-superpixel records (88 B each) sit in LDS too; without them eight chains fit a workgroup
+__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, bool rec_lds)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsLayout L;
     size_t o = 0;
-    L.fit = o; if (tab_lds) o += A((size_t)S * kRecStride * 8);
+    L.fit = o; if (tab_lds && rec_lds) o += A((size_t)S * kRecStride * 8);
     L.q = o; if (tab_lds) o += A((size_t)E2 * 8);
     L.col = o; if (tab_lds) o += A((size_t)E2 * 2);
     L.rowp = o; if (tab_lds) o += A((size_t)(S + 1) * 4);
@@ -201,7 +202,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
 
 constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
 
-template <int WPB, bool TAB_LDS, bool PROF>
+template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF>
 __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     const int S = a.S[frame];
     const int E2 = (int)a.E2[frame];
     const int NW = (S + 31) / 32;
-    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS);
+    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, REC_LDS);
 
     const double* g_fit = a.fit + (size_t)frame * a.s_max * kFitStride;
     const double* g_q = a.q + (size_t)frame * a.e2_max;
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     // ---- stage the frame tables (block-cooperative) ----
     if (TAB_LDS) {
+        if (REC_LDS)
         for (int i = tid; i < S * kRecStride; i += WPB * 64) {
             const int sp = i / kRecStride, k = i - sp * kRecStride;
             l_fit[i] = g_fit[(size_t)sp * kFitStride + (k < 9 ? k : k + 3)];
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     else { qv = g_q; rowp = g_rowp; }
     // sums of superpixel i: 0..8 the moments, 9 Sbb, 10 ssr
     auto recAt = [&](uint32_t i, int k) -> double {
-        if constexpr (TAB_LDS) return l_fit[(size_t)i * kRecStride + k];
+        if constexpr (TAB_LDS && REC_LDS) return l_fit[(size_t)i * kRecStride + k];
         else return g_fit[(size_t)i * kFitStride + (k < 9 ? k : k + 3)];
     };
     auto colAt = [&](uint32_t e) -> uint32_t {
@@ -814,22 +816,22 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int WPB, bool TAB, bool PROF = false>
+template <int WPB, bool TAB, bool REC = TAB, bool PROF = false>
 static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
 {
-    if constexpr (!PROF && WPB == 4 && TAB) {
-        if (a.prof) return launch_variant<4, true, true>(a, s_lds, e2_lds, bytes, st);
+    if constexpr (!PROF && WPB == 4 && TAB && REC) {
+        if (a.prof) return launch_variant<4, true, true, true>(a, s_lds, e2_lds, bytes, st);
     }
     static DeviceOnce once;
     bool* attr_done = once.slot();
     if (!attr_done || !*attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, PROF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, REC, PROF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
         if (attr_done) *attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
-    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, REC, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
     return hipGetLastError();
 }
 
@@ -840,7 +842,7 @@ size_t chain_run_global_slots(const ChainArgs& a, int s_used_max, int e2_used_ma
     const int wpbs[3] = { 4, 2, 1 };
     for (int wi = 0; wi < 3; ++wi) {
         if (a.chains_per_frame % wpbs[wi]) continue;
-        if (make_layout(s_used_max, e2_used_max, wpbs[wi], true).total <= cap) return 0;
+        if (make_layout(s_used_max, e2_used_max, wpbs[wi], true, true).total <= cap) return 0;
     }
     return queue_slots(s_used_max, e2_used_max);
 }
@@ -849,11 +851,23 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
 {
     const size_t cap = kLdsLimit - 64;
     const int wpbs[3] = { 4, 2, 1 };
+    // More chains than four per CU can hold at once: eight per workgroup, with the per-superpixel records read
+    // through L2 (only the component's rows, once per step) so that the CSR tables and eight private states fit LDS.
+    if (!a.prof && a.dense_variant >= 0 && a.chains_per_frame % 8 == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+            const LdsLayout L8 = make_layout(s_used_max, e2_used_max, 8, true, false);
+            if (L8.total <= cap && (a.dense_variant > 0 || a.n_chains > 4 * cus)) {
+                if (variant_out) *variant_out = 28;
+                return launch_variant<8, true, false>(a, s_used_max, e2_used_max, L8.total, st);
+            }
+        }
+    }
     for (int tab = 1; tab >= 0; --tab) {
         for (int wi = 0; wi < 3; ++wi) {
             const int wpb = wpbs[wi];
             if (a.chains_per_frame % wpb) continue;
-            const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0);
+            const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0, tab != 0);
             if (L.total > cap) continue;
             if (!tab && !a.slots_g) return hipErrorInvalidValue;
             if (variant_out) *variant_out = tab * 10 + wpb;

@@ -176,6 +176,28 @@ def test_chain_parity_small(scene_c2_small, gpu_ctx_factory):
     assert np.array_equal(ctx.marginals(0)[:sc.n_superpixels], orc.marginals())
 
 
+@pytest.mark.parametrize("dense", [1, -1])
+def test_chain_parity_dense_variant(scene_c2_small, gpu_ctx_factory, dense):
+    # eight chains per workgroup with the per-superpixel records read through L2 (picked by itself when the chains
+    # exceed four per CU; forced here), and the same job with the variant switched off: identical chains
+    sc = scene_c2_small
+    ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
+    ctx.frames_alloc(2, sc.n_superpixels, sc.col.size)
+    _load(ctx, 0, sc); _load(ctx, 1, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.set_option("k3_dense", dense)
+    n = 32
+    ctx.chains_init(n, chains_per_frame=16, seed=21)
+    ctx.chains_set_trace(260)
+    ctx.chains_run(60, 200)
+    tr = ctx.trace()
+    for f in range(2):
+        orc = _oracle_chains(sc, 16, seed=21, off=16 * f)
+        st, otr = orc.run(60, 200, trace=True)
+        assert st == 0 and np.array_equal(tr[16 * f:16 * f + 16], otr)
+        _compare_chains(ctx, orc, frame=f, lo=16 * f, hi=16 * f + 16)
+
+
 def test_chain_offset_sharding(scene_c2_small, gpu_ctx_factory):
     # a shard that owns chains [6, 10) of a 10-chain job reproduces them exactly (multi-GPU rule)
     sc = scene_c2_small

@@ -38,6 +38,8 @@ def run_c5():
     ctx.set_timing(True)
     ctx.frames_moments(); ctx.frames_edge_probs(); ctx.frames_moments(); ctx.frames_edge_probs()
     print("C5 (32 frames): K1 %.3f ms, K2 %.3f ms" % (ctx.last_kernel_ms(0), ctx.last_kernel_ms(2)))
+    if os.environ.get("DENSE"):
+        ctx.set_option("k3_dense", int(os.environ["DENSE"]))
     ctx.chains_init(F * cpf, chains_per_frame=cpf, seed=5)
     ctx.chains_run(1000, 0)
     iters = int(os.environ.get("ITERS5", 2000))
@@ -49,4 +51,5 @@ def run_c5():
     ctx.close()
 
 run_c5()
-run_c3()
+if not os.environ.get("ONLY_C5"):
+    run_c3()
