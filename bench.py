@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-multiview", action="store_true")
+    ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--mv-chains", type=int, default=1024)
     ap.add_argument("--mv-steps", type=int, default=20)
     return ap.parse_args()
@@ -174,6 +175,40 @@ def k1_roofline(host, sc_list, n_frames, reps, device):
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg, "min_launch_ms": float(np.min(ms)),
             "launches": reps, "traffic": traffic}
+
+
+def c5_share_line(host, sc_list, device, frames=32, cpf=64, iters=1000, steps=2):
+    """BASELINE configs[4] ("C5"), one GPU's share of the node: 32 of the 256 frames x 64 chains each; a step =
+    moments + local fits + edge probabilities of all frames, then `iters` sampler iterations of every chain.
+    Secondary line (the headline stays C2): the shape a multi-frame deployment runs."""
+    import torch
+    W, H = sc_list[0].width, sc_list[0].height
+    smax = max(s.n_superpixels for s in sc_list); emax = max(s.col.size for s in sc_list)
+    ctx = host.Context(width=W, height=H, device=device)
+    ctx.frames_alloc(frames, smax, emax)
+    for f in range(frames):
+        host.load_scene(ctx, f, sc_list[f % len(sc_list)])
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(frames * cpf, chains_per_frame=cpf, seed=5)
+    ctx.set_timing(True)
+
+    def step():
+        ctx.frames_moments(); ctx.frames_edge_probs(); ctx.chains_run(0, iters, sync=False)
+    step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    sca = ctx.scalars()
+    assert (sca["status"] == 0).all()
+    out = {"workload": "C5 share: %d frames x %d chains, %dx%d, step = moments + edge probs + %d iterations/chain"
+                       % (frames, cpf, W, H, iters),
+           "proposals_per_s": frames * cpf * iters * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "chain_kernel_ms": ctx.last_kernel_ms(host.K_CHAIN), "moments_kernel_ms": ctx.last_kernel_ms(host.K_MOMENTS)}
+    ctx.close()
+    return out
 
 
 def multiview_line(host, device, n_chains, steps):
@@ -305,9 +340,13 @@ def main():
     if rank == 0 and world == 1 and not a.no_multiview:
         out["multiview"] = multiview_line(host, local, a.mv_chains, a.mv_steps)
     if rank == 0 and world == 1:
-        if not a.no_roofline:
+        scs = None
+        if not a.no_roofline or not a.no_c5:
             scs = [sc] + [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=100 + i)
                           for i in range(3)]
+        if not a.no_c5:
+            out["c5_share"] = c5_share_line(host, scs, local)
+        if not a.no_roofline:
             out["roofline"] = k1_roofline(host, scs, a.roofline_frames, a.roofline_reps, local)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, a.seed, a.cpu_seconds)
