@@ -614,6 +614,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
             if (MODE == 1) {
+                int prof_pts = 0, prof_ev = 0;
                 for (int v = tid; v < V; v += kMvThreads) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
@@ -623,9 +624,13 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                     x.inE[(size_t)chain * V + v] = L.inE[v];
                     if (a.prof && (o == orig || o == target || ie)) {
                         // points of SB1 u SB2 (the algorithmic-bytes figure of SURVEY 8d) and evaluations asked for
-                        atomicAdd(a.prof + 10, (unsigned long long)(g.pt_ptr[v + 1] - g.pt_ptr[v]));
-                        atomicAdd(a.prof + 11, (unsigned long long)__popc(nb4));
+                        prof_pts += (int)(g.pt_ptr[v + 1] - g.pt_ptr[v]);
+                        prof_ev += __popc(nb4);
                     }
+                }
+                if (a.prof) {
+                    prof_pts = wave_sum_i32(prof_pts); prof_ev = wave_sum_i32(prof_ev);
+                    if (lane == 0) { atomicAdd(a.prof + 10, (unsigned long long)prof_pts); atomicAdd(a.prof + 11, (unsigned long long)prof_ev); }
                 }
             }
             if (MODE == 0)
