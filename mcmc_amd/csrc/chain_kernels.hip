@@ -31,7 +31,6 @@ namespace mc {
 constexpr int kLdsLimit = 160 * 1024;
 
 MC_D size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
-static inline size_t h_al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // ---- RNG: the uniform at position p of a step is word (p>>6)&3 of Philox block (p>>8)*64 + (p&63),
 // so the 64 lanes generate positions [256 b, 256 b + 256) with one Philox call each.
