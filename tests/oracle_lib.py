@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "oracle", "_build", "libmcmc_oracle.so")
+# MCMC_ORACLE_SO: an alternative build of the same sources (e.g. one compiled with -fsanitize=undefined)
+SO = os.environ.get("MCMC_ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "libmcmc_oracle.so")
 
 _lib = None
 
@@ -28,6 +29,8 @@ f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
 
 def build():
     """Compile the oracle with gcc if the .so is missing or stale."""
+    if os.environ.get("MCMC_ORACLE_SO"):
+        return
     srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
             if f.endswith((".c", ".cpp"))]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
