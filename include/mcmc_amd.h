@@ -147,6 +147,12 @@ int mcmc_set_timing(mcmc_ctx *ctx, int enable);
  * "k1_threads", "k1_use_lds", "k1_debug", "k3_profile", "k3_dense" (eight chains per workgroup with the records
  * read through L2: -1 never, 0 when the chains exceed four per CU, 1 always).  Results never depend on them. */
 int mcmc_ctx_set_option(mcmc_ctx *ctx, const char *name, int value);
+/* Diagnostic (no counterpart in the reference): which form of the chain kernel the last mcmc_chains_run
+ * launched, as 10 * placement + chains per workgroup; placement 1 = all frame tables in LDS, 2 = tables in LDS
+ * except the per-superpixel records (eight chains per workgroup), 3 = only the CSR topology in LDS (large frames),
+ * 0 = everything behind L2.  Results never depend on it. */
+int mcmc_chains_last_variant(const mcmc_ctx *ctx);
+
 /* After option "k3_profile" = 1 and a run: shader-clock cycles summed over chains for 12
  * phases of the step, then sums of component size, draws and refit members (diagnostic build of the chain kernel; never used for reported numbers). */
 int mcmc_chains_get_profile(mcmc_ctx *ctx, uint64_t *out16);

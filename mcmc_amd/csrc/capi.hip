@@ -565,6 +565,11 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
     return MCMC_OK;
 }
 
+int mcmc_chains_last_variant(const mcmc_ctx* c)
+{
+    return c ? c->chain_variant : MCMC_E_BADARG;
+}
+
 int mcmc_chains_get_profile(mcmc_ctx* c, uint64_t* out12)
 {
     if (!c || !out12 || !c->d_prof) return fail(c, MCMC_E_STATE, "chains_get_profile: set option k3_profile and run first");

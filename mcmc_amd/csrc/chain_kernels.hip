@@ -159,15 +159,16 @@ __host__ __device__ inline size_t queue_slots(int S, int E2) { return (size_t)S 
 // The FIFO lives in LDS next to the tables; frames whose tables do not fit keep it in HBM too (a.slots_g), which
 // leaves room for several chains per workgroup.
 // rec_lds: the per-superpixel records (88 B each) sit in LDS too; without them eight chains fit a workgroup
-__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, bool rec_lds)
+// topo_lds: frames whose tables do not fit keep at least the CSR topology (row pointers, u16 columns) in LDS
+__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, bool rec_lds, bool topo_lds = false)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsLayout L;
     size_t o = 0;
     L.fit = o; if (tab_lds && rec_lds) o += A((size_t)S * kRecStride * 8);
     L.q = o; if (tab_lds) o += A((size_t)E2 * 8);
-    L.col = o; if (tab_lds) o += A((size_t)E2 * 2);
-    L.rowp = o; if (tab_lds) o += A((size_t)(S + 1) * 4);
+    L.col = o; if (tab_lds || topo_lds) o += A((size_t)E2 * 2);
+    L.rowp = o; if (tab_lds || topo_lds) o += A((size_t)(S + 1) * 4);
     L.vlist = o; o += A((size_t)S * 2);
     L.sv = o; o += 16;
     L.wave0 = o;
@@ -201,7 +202,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
 
 constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
 
-template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF>
+template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF, bool TOPO_LDS = false>
 __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     const int S = a.S[frame];
     const int E2 = (int)a.E2[frame];
     const int NW = (S + 31) / 32;
-    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, REC_LDS);
+    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, REC_LDS, TOPO_LDS);
 
     const double* g_fit = a.fit + (size_t)frame * a.s_max * kFitStride;
     const double* g_q = a.q + (size_t)frame * a.e2_max;
@@ -228,13 +229,15 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     uint16_t* vlist = reinterpret_cast<uint16_t*>(smem + L.vlist);
 
     // ---- stage the frame tables (block-cooperative) ----
-    if (TAB_LDS) {
-        if (REC_LDS)
+    if (TAB_LDS && REC_LDS) {
         for (int i = tid; i < S * kRecStride; i += WPB * 64) {
             const int sp = i / kRecStride, k = i - sp * kRecStride;
             l_fit[i] = g_fit[(size_t)sp * kFitStride + (k < 9 ? k : k + 3)];
         }
-        for (int i = tid; i < E2; i += WPB * 64) { l_q[i] = g_q[i]; l_col[i] = (uint16_t)g_col[i]; }
+    }
+    if (TAB_LDS) for (int i = tid; i < E2; i += WPB * 64) l_q[i] = g_q[i];
+    if (TAB_LDS || TOPO_LDS) {
+        for (int i = tid; i < E2; i += WPB * 64) l_col[i] = (uint16_t)g_col[i];
         for (int i = tid; i <= S; i += WPB * 64) l_rowp[i] = g_rowp[i];
     }
     // list of superpixels that passed the A1 filter, ascending (wave 0)
@@ -264,15 +267,15 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     // ---- table accessors: LDS or HBM/L2 ----
     const double* qv; const uint32_t* rowp;
-    if constexpr (TAB_LDS) { qv = l_q; rowp = l_rowp; }
-    else { qv = g_q; rowp = g_rowp; }
+    if constexpr (TAB_LDS) qv = l_q; else qv = g_q;
+    if constexpr (TAB_LDS || TOPO_LDS) rowp = l_rowp; else rowp = g_rowp;
     // sums of superpixel i: 0..8 the moments, 9 Sbb, 10 ssr
     auto recAt = [&](uint32_t i, int k) -> double {
         if constexpr (TAB_LDS && REC_LDS) return l_fit[(size_t)i * kRecStride + k];
         else return g_fit[(size_t)i * kFitStride + (k < 9 ? k : k + 3)];
     };
     auto colAt = [&](uint32_t e) -> uint32_t {
-        if constexpr (TAB_LDS) return (uint32_t)l_col[e]; else return g_col[e];
+        if constexpr (TAB_LDS || TOPO_LDS) return (uint32_t)l_col[e]; else return g_col[e];
     };
 
     // ---- wave-private state ----
@@ -885,7 +888,7 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int WPB, bool TAB, bool REC = TAB, bool PROF = false>
+template <int WPB, bool TAB, bool REC = TAB, bool PROF = false, bool TOPO = false>
 static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
 {
     if constexpr (!PROF && WPB == 4 && TAB && REC) {
@@ -894,13 +897,13 @@ static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size
     static DeviceOnce once;
     bool* attr_done = once.slot();
     if (!attr_done || !*attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, REC, PROF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, REC, PROF, TOPO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
         if (attr_done) *attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
-    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, REC, PROF>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, REC, PROF, TOPO>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
     return hipGetLastError();
 }
 
@@ -933,6 +936,21 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
         }
     }
     for (int tab = 1; tab >= 0; --tab) {
+        if (!tab && a.dense_variant >= 0 && s_used_max <= 0xFFFF) {
+            // tables too large for LDS: keep at least the CSR topology there (two of the four dependent round trips
+            // of a growth pass), q, records and the FIFO behind L2
+            for (int wi = 0; wi < 3; ++wi) {
+                const int wpb = wpbs[wi];
+                if (a.chains_per_frame % wpb) continue;
+                const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, false, false, true);
+                if (L.total > cap) continue;
+                if (!a.slots_g) return hipErrorInvalidValue;
+                if (variant_out) *variant_out = 30 + wpb;
+                if (wpb == 4) return launch_variant<4, false, false, false, true>(a, s_used_max, e2_used_max, L.total, st);
+                if (wpb == 2) return launch_variant<2, false, false, false, true>(a, s_used_max, e2_used_max, L.total, st);
+                return launch_variant<1, false, false, false, true>(a, s_used_max, e2_used_max, L.total, st);
+            }
+        }
         for (int wi = 0; wi < 3; ++wi) {
             const int wpb = wpbs[wi];
             if (a.chains_per_frame % wpb) continue;

@@ -114,6 +114,7 @@ def load():
         "mcmc_mv_chains_get_scalars": (i, [vp] + [vp] * 6),
         "mcmc_mv_chains_get_planes": (i, [vp, i, vp]),
         "mcmc_mv_chains_get_profile": (i, [vp, vp]),
+        "mcmc_chains_last_variant": (i, [vp]),
         "mcmc_mv_last_run_ms": (dbl, [vp]),
         "mcmc_overseg_default_params": (None, [C.POINTER(OversegParams)]),
         "mcmc_overseg_create": (i, [i, i, i, C.POINTER(vp)]),
@@ -277,6 +278,10 @@ class Context:
         out = np.zeros(self.n_chains)
         self._ck(self.L.mcmc_chains_recompute_energy(self.h, _ptr(out, np.float64)))
         return out
+
+    def last_variant(self):
+        """10 * table placement + chains per workgroup of the last chains_run (diagnostic)."""
+        return int(self.L.mcmc_chains_last_variant(self.h))
 
     # ---- plumbing / measurement
     def set_stream(self, hip_stream_handle):

@@ -190,6 +190,7 @@ def test_chain_parity_dense_variant(scene_c2_small, gpu_ctx_factory, dense):
     ctx.chains_init(n, chains_per_frame=16, seed=21)
     ctx.chains_set_trace(260)
     ctx.chains_run(60, 200)
+    assert ctx.last_variant() == (28 if dense == 1 else 14)
     tr = ctx.trace()
     for f in range(2):
         orc = _oracle_chains(sc, 16, seed=21, off=16 * f)
@@ -241,17 +242,22 @@ def test_chain_parity_c2_full_size(gpu_ctx_factory):
     assert np.array_equal(ctx.scalars()["trace_hash"], s["trace_hash"])
 
 
-def test_chain_parity_large_s_global_tables(gpu_ctx_factory):
-    # tables that do not fit LDS (config 3 style: ~1500 superpixels here) take the HBM/L2-table variant
+@pytest.mark.parametrize("placement", [3, 0])
+def test_chain_parity_large_s_global_tables(gpu_ctx_factory, placement):
+    # tables that do not fit LDS (config 3 style: ~1500 superpixels here): the CSR topology alone in LDS
+    # (placement 3, picked by itself), and everything behind L2 (placement 0, which still larger frames take)
     from mcmc_amd.scene import make_scene
     sc = make_scene(width=960, height=540, n_planes=10, n_superpixels=1500, seed=2)
     ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
     ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
     _load(ctx, 0, sc)
     ctx.frames_moments(); ctx.frames_edge_probs()
+    if placement == 0:
+        ctx.set_option("k3_dense", -1)
     ctx.chains_init(6, chains_per_frame=6, seed=3)
     ctx.chains_set_trace(120)
     ctx.chains_run(40, 80)
+    assert ctx.last_variant() // 10 == placement
     orc = _oracle_chains(sc, 6, seed=3)
     st, tr = orc.run(40, 80, trace=True)
     assert np.array_equal(ctx.trace(), tr)
