@@ -649,8 +649,21 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             __syncthreads();
             // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
             if (MODE != 1 && !sh->have[wave]) {
+                // four rows per trip, fetched whether or not they are members (in the split iteration the table is
+                // behind L2 and a fetch per member would be one round trip after the other); only members are
+                // added, in vertex order
                 double part = 0.0;
-                for (int v = lane; v < V; v += kWave) if (member(wave, v)) part += L.errv[(size_t)wave * V + v];
+                for (int v0 = lane; v0 < V; v0 += 4 * kWave) {
+                    double tv[4]; bool in[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int v = v0 + u * kWave;
+                        in[u] = v < V && member(wave, v);
+                        tv[u] = L.errv[(size_t)wave * V + (v < V ? v : V - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (in[u]) part += tv[u];
+                }
                 const double err = wave_sum_f64(part);
                 const double p = prob_from_error(err, sh->pl[wave][4]);
                 if (lane == 0) {
