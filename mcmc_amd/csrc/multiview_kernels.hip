@@ -171,7 +171,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_fit_segment_kernel(MvGraph g, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* errv = reinterpret_cast<double*>(smem);
     double* pl = errv + g.V;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave index as a scalar: the loops over "this wave's" vertices then get scalar control flow
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     if (wave == 0) {
         double m[10], p5[5];
         pool_moments(g.vm, g.V, lane, [&](int v) { return mem[v] != 0; }, m);
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
     const int V = g.V;
     MvLds L = mv_carve(smem, V, false);
     const int chain = (int)blockIdx.x;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave index as a scalar: the loops over "this wave's" vertices then get scalar control flow
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = 0xFFFFu; L.se[v] = 0u; }
     __syncthreads();
     {
@@ -312,9 +314,9 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
             while (head < tail) {
                 uint32_t cn = 0;
                 for (uint32_t vi = head + (uint32_t)wave; vi < tail; vi += kMvWaves) {
-                    const uint32_t v = L.elist[vi];
-                    const uint32_t e1 = g.rowp[v + 1];
-                    for (uint32_t e0 = g.rowp[v]; e0 < e1; e0 += kWave) {
+                    const uint32_t v = uni((uint32_t)L.elist[vi]);
+                    const uint32_t e1 = uni(g.rowp[v + 1]);
+                    for (uint32_t e0 = uni(g.rowp[v]); e0 < e1; e0 += kWave) {
                         const uint32_t e = e0 + (uint32_t)lane;
                         uint32_t j = 0;
                         bool cand = false;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
                 }
                 if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
                 __syncthreads();
-                head = tail; tail = L.sh->nE;
+                head = tail; tail = uni(L.sh->nE);
                 __syncthreads();
             }
             ncomp++;
@@ -385,7 +387,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     MvLds L = mv_carve(smem, V, MODE == 0);
     MvShared* sh = L.sh;
     const int chain = (int)blockIdx.x;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave index as a scalar: the loops over "this wave's" vertices then get scalar control flow
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     uint16_t* gcur = a.cur + (size_t)chain * V;
     uint16_t* gown = a.own + (size_t)chain * V;
     double* planes = a.plane + (size_t)chain * a.seg_cap * 5;
@@ -453,11 +456,11 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 // a wave's frontier vertices in turn; the CSR bounds of the next one are fetched under the
                 // scan of the current one, and up to 256 of its out-edges are loaded before any is looked at
                 uint32_t vi = head + (uint32_t)wave, r0 = 0, e1 = 0;
-                if (vi < tail) { const uint32_t v = L.elist[vi]; r0 = g.rowp[v]; e1 = g.rowp[v + 1]; }
+                if (vi < tail) { const uint32_t v = uni((uint32_t)L.elist[vi]); r0 = uni(g.rowp[v]); e1 = uni(g.rowp[v + 1]); }
                 while (vi < tail) {
                     const uint32_t vn = vi + (uint32_t)kMvWaves;
-                    uint32_t nr0 = 0, ne1 = 0;
-                    if (vn < tail) { const uint32_t v = L.elist[vn]; nr0 = g.rowp[v]; ne1 = g.rowp[v + 1]; }
+                    uint32_t nr0 = 0, ne1 = 0;      // made scalar where they are used, so the fetch stays in flight
+                    if (vn < tail) { const uint32_t v = uni((uint32_t)L.elist[vn]); nr0 = g.rowp[v]; ne1 = g.rowp[v + 1]; }
                     for (uint32_t eb = r0; eb < e1; eb += 4u * kWave) {
                         uint32_t jj[4];
 #pragma unroll
@@ -492,11 +495,11 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                             }
                         }
                     }
-                    vi = vn; r0 = nr0; e1 = ne1;
+                    vi = vn; r0 = uni(nr0); e1 = uni(ne1);
                 }
                 if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
                 __syncthreads();
-                head = tail; tail = sh->nE;
+                head = tail; tail = uni(sh->nE);
                 __syncthreads();
             }
             stamp(2);
