@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = uni(tid >> 6);            // scalar: addresses derived from it stay in SGPRs
     const int lane = tid & 63;
     const int chain0 = (int)blockIdx.x * WPB;
     const int frame = chain0 / a.chains_per_frame;
