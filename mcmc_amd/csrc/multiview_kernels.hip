@@ -779,7 +779,7 @@ MC_D void err_block(const MvGraph& g, int n_chains, const MvExchange& x, int v, 
 __global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
 {
     const int lane = (int)threadIdx.x & 63;
-    const int v = (int)(blockIdx.x * kMvWaves + (threadIdx.x >> 6));
+    const int v = uni((int)(blockIdx.x * kMvWaves + (threadIdx.x >> 6)));     // scalar, and so are its CSR bounds
     if (v >= g.V) return;
     const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
     {   // nothing wanted from this vertex by these chains: leave before touching its points
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_
         }
         if (!__ballot(any)) return;
     }
-    const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
+    const uint32_t b = uni(g.pt_ptr[v]), e = uni(g.pt_ptr[v + 1]);
     const uint32_t cnt = e - b;
     // the vertex's points, widened once: every (chain, plane) evaluation is then arithmetic only
     double px[kErrRegPts], py[kErrRegPts], pz[kErrRegPts];
