@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
         if (tid == 0) L.sh->nn = ncomp;
     }
     __syncthreads();
-    const int nseg = L.sh->nn;
+    const int nseg = uni(L.sh->nn);
     uint16_t* gcur = a.cur + (size_t)chain * V;
     uint16_t* gown = a.own + (size_t)chain * V;
     for (int v = tid; v < V; v += kMvThreads) { gcur[v] = L.cur[v]; gown[v] = L.cur[v]; }
