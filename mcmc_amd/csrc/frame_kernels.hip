@@ -598,7 +598,7 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     const int band = (int)blockIdx.x;
     const int S = a.S[frame];
     const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = uni(tid >> 6);
     const int W = a.W, H = a.H, G = W / 8;
     unsigned long long* gmom = a.mom + (size_t)frame * a.s_max * kMomStride;
     unsigned long long* tab = TABLE_LDS ? lds : gmom;
