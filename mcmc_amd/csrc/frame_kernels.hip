@@ -578,6 +578,12 @@ MC_D void gload16(u32x4v& dst, const void* p)
 {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+// the same with the frame's base address in an SGPR pair and a 32-bit byte offset per lane (one VALU add per
+// load instead of 64-bit address arithmetic)
+MC_D void gload16s(u32x4v& dst, uint32_t byte_off, const void* sbase)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
+}
 template <int N>
 MC_D void wait_vm(u32x4v& a, u32x4v& b)
 {
@@ -637,11 +643,12 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     // index clamped per lane; the last reloads re-read the strip's last row), otherwise the count of
     // younger loads would not be the constant the wait relies on.
     const int cl = max(count, 1);
-    const uint32_t safe0 = (uint32_t)(min(rs, H - 1) * G + g);          // < 2^21 uint4 per frame
+    const uint32_t safe0 = (uint32_t)(min(rs, H - 1) * G + g) * 16u;    // byte offset, < 2^25 per frame
+    const int G16 = G * 16;
     auto load_row = [&](const int j, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
-        const uint32_t o = safe0 + (uint32_t)__mul24(RAGGED ? min(j, cl - 1) : min(j, R - 1), G);
-        gload16(d4, dpf + o);
-        gload16(l4, lpf + o);
+        const uint32_t o = safe0 + (uint32_t)__mul24(RAGGED ? min(j, cl - 1) : min(j, R - 1), G16);
+        gload16s(d4, o, dpf);
+        gload16s(l4, o, lpf);
     };
     u32x4v dA = 0, lA = 0, dB = 0, lB = 0, dC = 0, lC = 0, dD = 0, lD = 0;
     load_row(0, dA, lA);
