@@ -287,6 +287,80 @@ def test_multi_frame_batch(gpu_ctx_factory):
         assert np.array_equal(ctx.marginals(f)[:sc.n_superpixels], orc.marginals())
 
 
+def _properties(ctx, S, frames, cpf, burn, iters):
+    """Size-independent checks over every chain of a job (the oracle only re-runs a few of them)."""
+    s = ctx.scalars()
+    assert (s["status"] == 0).all()
+    assert (s["n_case"].sum(axis=1) == burn + iters).all()
+    assert np.allclose(s["energy"], ctx.recompute_energy(), rtol=1e-9)
+    assert (s["best_energy"] >= s["energy"]).all()
+    v = ctx.visits()
+    assert all(sum(d.values()) + int(o) == iters for d, o in zip(v, s["overflow"]))
+    for f in range(frames):
+        m = ctx.marginals(f)[:S[f]]
+        assert (m.sum(axis=1) == cpf * iters).all(), f
+    return s
+
+
+def test_chain_parity_c3_full_size(gpu_ctx_factory):
+    # BASELINE config 3 at full size: 1920x1080, ~4500 superpixels, one GPU's share of the 4096 chains (512).
+    # The tables (~640 KB) do not fit LDS: placement 3 (CSR topology in LDS, the rest behind L2).
+    from mcmc_amd.scene import make_scene
+    sc = make_scene(width=1920, height=1080, n_planes=24, n_superpixels=4000, seed=2)
+    S = sc.n_superpixels
+    assert S > 4000
+    ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
+    ctx.frames_alloc(1, S, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    # 4 chains x 100 steps, trace-exact against the oracle
+    ctx.chains_init(4, seed=2)
+    ctx.chains_set_trace(100)
+    ctx.chains_run(30, 70)
+    assert ctx.last_variant() // 10 == 3
+    orc = _oracle_chains(sc, 4, seed=2)
+    st, tr = orc.run(30, 70, trace=True)
+    assert st == 0 and np.array_equal(ctx.trace(), tr)
+    _compare_chains(ctx, orc)
+    assert np.array_equal(ctx.marginals(0)[:S], orc.marginals())
+    # the share of one GPU: chains [1024, 1536) of the 4096 (rank 2 of 8), properties over all of them and the
+    # first three against the oracle run with the same global ids
+    ctx.chains_init(512, seed=2, chain_offset=1024)
+    ctx.chains_run(50, 150)
+    assert ctx.last_variant() // 10 == 3
+    s = _properties(ctx, [S], 1, 512, 50, 150)
+    orc = _oracle_chains(sc, 3, seed=2, off=1024)
+    orc.run(50, 150)
+    assert np.array_equal(s["trace_hash"][:3], orc.scalars()["trace_hash"])
+    assert np.array_equal(ctx.labels()[:3, :S], orc.labels())
+
+
+def test_chain_parity_c5_share_full_size(gpu_ctx_factory):
+    # BASELINE config 5, one GPU's share: 32 frames of 640x480 (~500 superpixels), 64 chains each = 2048 chains,
+    # more than four per CU, so eight chains share a workgroup with the records behind L2 (variant 28).
+    from mcmc_amd.scene import make_scene
+    F, cpf, burn, iters = 32, 64, 40, 160
+    scenes = [make_scene(seed=100 + f) for f in range(F)]
+    smax = max(s.n_superpixels for s in scenes); emax = max(s.col.size for s in scenes)
+    ctx = gpu_ctx_factory()
+    ctx.frames_alloc(F, smax, emax)
+    for f, sc in enumerate(scenes):
+        _load(ctx, f, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(F * cpf, chains_per_frame=cpf, seed=5)
+    ctx.chains_run(burn, iters)
+    assert ctx.last_variant() == 28
+    s = _properties(ctx, [sc.n_superpixels for sc in scenes], F, cpf, burn, iters)
+    lab = ctx.labels()
+    for f in (0, 13, 31):
+        sc = scenes[f]
+        assert np.array_equal(ctx.moments(f), O.moments(sc.disp, sc.label, sc.n_superpixels))
+        orc = _oracle_chains(sc, 2, seed=5, off=f * cpf)
+        orc.run(burn, iters)
+        assert np.array_equal(s["trace_hash"][f * cpf:f * cpf + 2], orc.scalars()["trace_hash"]), f
+        assert np.array_equal(lab[f * cpf:f * cpf + 2, :sc.n_superpixels], orc.labels()), f
+
+
 def test_error_paths(gpu_ctx_factory):
     from mcmc_amd import host
     ctx = gpu_ctx_factory(width=64, height=32)
