@@ -101,6 +101,16 @@ int mcmc_frame_get_edge_probs(mcmc_ctx *ctx, int frame, double *q /* e2; -1 = ed
 int mcmc_segment_probability(mcmc_ctx *ctx, int frame, const uint32_t *members, int n_members,
                              double *probL, double *theta3, double *err);
 
+/* No counterpart in the reference.  mcmc_segment_probability for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same result bit
+ * for bit, but the membership bytes, the member list and the result are staged in a static device array of the
+ * library (328 KB per GPU, held until the process ends) instead of buffers the context allocates, and the call
+ * makes no hipMalloc / hipFree.  Limits: n_members <= 65536 and at most 65536 superpixels, else MCMC_E_TOO_LARGE.
+ * Every context on one GPU shares that GPU's array: calls that overlap on one GPU (two host threads, two
+ * contexts) race; calls one after the other are safe, each clears what it needs. */
+int mcmc_segment_probability_noalloc(mcmc_ctx *ctx, int frame, const uint32_t *members, int n_members,
+                                     double *probL, double *theta3, double *err);
+
 /* ---- chains: Problem::initializeState + MCMC<Problem>::run with
  * FastMetropolisHastings::iterate (Problem.cpp:447-473, 116-224; MCMC.h:43-89,
  * 207-238; Segmentation.cpp:10-237; Statistics.h:33-70). -------------------- */

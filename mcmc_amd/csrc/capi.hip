@@ -19,6 +19,19 @@
 
 using namespace mc;
 
+// ---- static scratch of the allocation-free entry point (mcmc_segment_probability_noalloc) -----------------
+// Device memory that exists from load time on every GPU the library runs on, so the entry point never calls
+// hipMalloc.  Layout: [0, 256) result doubles | [256, 256 + 65536) membership bytes | then 65536 member ids.
+// In host code `scratch` is only a handle for hipGetSymbolAddress: the device address is taken once per device
+// in mcmc_ctx_create (with that device current) and kept in g_scratch[device]; host code uses that pointer only.
+constexpr int kScratchMaxS = 65536;            // superpixels (the ABI's s_max is < 65535 anyway)
+constexpr int kScratchMaxMembers = 65536;      // ids in one member list
+constexpr size_t kScratchOutOff = 0, kScratchMemOff = 256, kScratchListOff = 256 + (size_t)kScratchMaxS;
+constexpr size_t kScratchBytes = kScratchListOff + (size_t)kScratchMaxMembers * 4;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char* g_scratch[kMaxDevices];  // per device: each GPU holds its own copy at its own address
+
 namespace {
 
 enum { K_MOM = 0, K_FIT = 1, K_EDGE = 2, K_CHAIN = 3, K_COUNT = 4 };
@@ -170,6 +183,12 @@ int mcmc_ctx_create(int device, const mcmc_params* params, mcmc_ctx** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return MCMC_E_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return MCMC_E_DEVICE;
+    if (device < kMaxDevices && !g_scratch[device]) {
+        // the device current now is the one whose copy of the array this address belongs to
+        unsigned char* sp = nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&sp), HIP_SYMBOL(scratch)) != hipSuccess || !sp) return MCMC_E_DEVICE;
+        g_scratch[device] = sp;
+    }
     mcmc_ctx* c = new mcmc_ctx();
     c->device = device; c->p = p;
     c->px = (size_t)p.width * (size_t)p.height;
@@ -474,6 +493,41 @@ int mcmc_segment_probability(mcmc_ctx* c, int frame, const uint32_t* members, in
     HIPCHK(c, launch_segment_prob(a, c->stream));
     double out[6];
     HIPCHK(c, hipMemcpyAsync(out, c->d_segout, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (probL) *probL = out[0];
+    if (err) *err = out[1];
+    if (theta3) { theta3[0] = out[2]; theta3[1] = out[3]; theta3[2] = out[4]; }
+    if (out[5] != 0.0) return fail(c, MCMC_E_INF_ENERGY, "The subgraph log probability is inf");
+    return MCMC_OK;
+}
+
+// Same result as mcmc_segment_probability without any device allocation: the membership bytes, the member list
+// and the result are staged in the library's static scratch (one per GPU, shared by every context on it).
+int mcmc_segment_probability_noalloc(mcmc_ctx* c, int frame, const uint32_t* members, int n, double* probL, double* theta3, double* err)
+{
+    if (!frame_ok(c, frame) || !members || n <= 0) return fail(c, MCMC_E_BADARG, "segment_probability_noalloc: bad argument");
+    if (!c->st_mom[frame]) return fail(c, MCMC_E_STATE, "segment_probability_noalloc: moments not computed");
+    const int S = c->h_S[frame];
+    if (n > kScratchMaxMembers || S > kScratchMaxS)
+        return fail(c, MCMC_E_TOO_LARGE, "segment_probability_noalloc: at most 65536 member ids and 65536 superpixels fit the static scratch");
+    for (int k = 0; k < n; ++k)
+        if (members[k] >= (uint32_t)S) return fail(c, MCMC_E_BADARG, "segment_probability_noalloc: member id out of range");
+    if (c->device >= kMaxDevices || !g_scratch[c->device]) return fail(c, MCMC_E_DEVICE, "segment_probability_noalloc: no scratch address for this device");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned char* sp = g_scratch[c->device];
+    double* d_out = reinterpret_cast<double*>(sp + kScratchOutOff);
+    uint8_t* d_mem = sp + kScratchMemOff;
+    uint32_t* d_list = reinterpret_cast<uint32_t*>(sp + kScratchListOff);
+    // the scratch keeps the last call's contents: the membership bytes must start at zero
+    HIPCHK(c, hipMemsetAsync(d_mem, 0, (size_t)S, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_list, members, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_mark_members(d_list, n, d_mem, c->stream));
+    SegArgs a{};
+    a.fit = c->d_fit + (size_t)frame * c->s_max * MCMC_FIT_STRIDE; a.mem = d_mem; a.out = d_out;
+    a.var = c->p.disparity_variance; a.S = S;
+    HIPCHK(c, launch_segment_prob(a, c->stream));
+    double out[6];
+    HIPCHK(c, hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (probL) *probL = out[0];
     if (err) *err = out[1];

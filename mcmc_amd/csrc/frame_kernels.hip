@@ -893,6 +893,14 @@ __global__ __launch_bounds__(64) void segment_prob_kernel(SegArgs a)
     }
 }
 
+// Member list -> membership bytes (the allocation-free entry point stages the list in the library's static
+// scratch; mem[0..S) was cleared on the stream before).  Duplicate ids write the same 1.
+__global__ void mark_members_kernel(const uint32_t* list, int n, uint8_t* mem)
+{
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < n) mem[list[k]] = 1;
+}
+
 // ---------------------------------------------------------------------------
 // Device self-tests of the shared math (parity of det_log/det_exp/division/Philox).
 // ---------------------------------------------------------------------------
@@ -988,6 +996,13 @@ hipError_t launch_edge_prob(const EdgeArgs& a, int n_frames, hipStream_t st)
 hipError_t launch_segment_prob(const SegArgs& a, hipStream_t st)
 {
     hipLaunchKernelGGL(segment_prob_kernel, dim3(1), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_members(const uint32_t* list, int n, uint8_t* mem, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_members_kernel, dim3((n + 255) / 256), dim3(256), 0, st, list, n, mem);
     return hipGetLastError();
 }
 

@@ -98,6 +98,7 @@ size_t moments_lr_lds_bytes(int table_rows, int threads);
 hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st);
 hipError_t launch_edge_prob(const EdgeArgs& a, int n_frames, hipStream_t st);
 hipError_t launch_segment_prob(const SegArgs& a, hipStream_t st);
+hipError_t launch_mark_members(const uint32_t* list, int n, uint8_t* mem, hipStream_t st);  // list ids < size of mem (checked by the caller)
 hipError_t launch_selftest_math(const double* x, const double* y, int n, double* ol, double* oe, double* od, hipStream_t st);
 hipError_t launch_selftest_philox(const uint32_t* ck, uint32_t* out, hipStream_t st);
 

@@ -80,6 +80,7 @@ def load():
         "mcmc_frame_get_local_fit": (i, [vp, i, vp, vp, vp]),
         "mcmc_frame_get_edge_probs": (i, [vp, i, vp]),
         "mcmc_segment_probability": (i, [vp, i, vp, i, C.POINTER(dbl), vp, C.POINTER(dbl)]),
+        "mcmc_segment_probability_noalloc": (i, [vp, i, vp, i, C.POINTER(dbl), vp, C.POINTER(dbl)]),
         "mcmc_chains_init": (i, [vp, i, i, u32, u32]),
         "mcmc_chains_run": (i, [vp, u64, u64]),
         "mcmc_chains_set_trace": (i, [vp, u64]),
@@ -225,6 +226,14 @@ class Context:
         p = C.c_double(); e = C.c_double(); th = np.zeros(3)
         self._ck(self.L.mcmc_segment_probability(self.h, frame, _ptr(m, np.uint32), m.size, C.byref(p),
                                                  _ptr(th, np.float64), C.byref(e)))
+        return p.value, th, e.value
+
+    def segment_probability_noalloc(self, frame, members):
+        """mcmc_segment_probability through the library's static scratch: no device allocation."""
+        m = np.ascontiguousarray(members, np.uint32)
+        p = C.c_double(); e = C.c_double(); th = np.zeros(3)
+        self._ck(self.L.mcmc_segment_probability_noalloc(self.h, frame, _ptr(m, np.uint32), m.size, C.byref(p),
+                                                         _ptr(th, np.float64), C.byref(e)))
         return p.value, th, e.value
 
     # ---- chains
