@@ -14,6 +14,17 @@ pass of the hot path over that batch, inputs already resident in HBM:
 Multi-GPU: chains are sharded by global chain id (weak scaling: 1024 chains per
 GPU, Philox key = global id), no collective inside the timed region.
 
+`--gpus N` without an external launcher (no WORLD_SIZE in the environment) starts the N ranks itself: the parent
+runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
+flags>` as a child process before anything touches a GPU, relays rank 0's JSON line and exits with the child's
+code.  A world that differs from --gpus is an error (exit 2), never a silently smaller run.
+
+`--config c2` (default, the headline): weak scaling, `--chains` chains per GPU.
+`--config c3`: BASELINE configs[2], one 1920x1080 frame (~4500 superpixels), `--total-chains` (4096) chains sharded
+              over the ranks by contiguous global id (strong scaling), marginals all-reduced.
+`--config c5`: BASELINE configs[4], `--total-frames` (256) frames x 64 chains, frames sharded over the ranks
+              (strong scaling), marginals all-gathered.
+
 Extra objects on the JSON line:
   roofline     -- the moment-accumulation kernel (north_star's HBM target) on a
                   256-frame batch (C5 shape, 324.8 MB algorithmic), timed with HIP
@@ -37,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -54,7 +65,67 @@ def parse():
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--mv-chains", type=int, default=1024)
     ap.add_argument("--mv-steps", type=int, default=20)
-    return ap.parse_args()
+    ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2")
+    ap.add_argument("--visit-capacity", type=int, default=0,
+                    help="distinct states counted per chain (Statistics); 0 = sized from the run by the library")
+    ap.add_argument("--total-chains", type=int, default=4096, help="c3: chains over all GPUs")
+    ap.add_argument("--total-frames", type=int, default=256, help="c5: frames over all GPUs")
+    ap.add_argument("--chains-per-frame", type=int, default=64, help="c5")
+    ap.add_argument("--distinct-scenes", type=int, default=8, help="c5: distinct synthetic scenes cycled over the frames")
+    return ap.parse_args(argv)
+
+
+def launch_plan(a, argv, env):
+    """How this invocation gets its ranks.  Returns None when this process is itself a rank (N == 1, or started
+    by torchrun: WORLD_SIZE set), else (command, environment) of the child that starts N ranks.  Pure function of
+    its arguments (tests/test_bench_launch.py) -- nothing here touches a GPU."""
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in env:
+        if int(env["WORLD_SIZE"]) != a.gpus:
+            print("bench.py: WORLD_SIZE=%s but --gpus %d" % (env["WORLD_SIZE"], a.gpus), file=sys.stderr)
+            raise SystemExit(2)                   # the world that runs must be the one asked for
+        return None
+    if a.gpus == 1:
+        return None
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    child = dict(env)
+    child.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this host driver)
+    child.setdefault("MASTER_ADDR", "127.0.0.1")
+    return cmd, child
+
+
+def run_children(cmd, env):
+    """Parent of a self-launched multi-rank run: never touches the GPU, relays rank 0's JSON line."""
+    import subprocess
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        raise SystemExit(p.returncode)
+    if line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        raise SystemExit(3)
+    print(line)
+    raise SystemExit(0)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(sc, seed, seconds):
@@ -76,35 +147,36 @@ def cpu_baseline(sc, seed, seconds):
         t_meas += time.perf_counter() - t1
         done += iters
         k += 1
-    cpu = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
+    cpu = cpu_model()
     return {"value": done / t_meas, "unit": "proposals/s", "cores": 1, "kind": "port",
             "sample": f"{k} chains x ({burn} burn-in + {iters} measured) steps of the same C2 scene, "
                       f"oracle/mcmc_oracle.c -O2 -ffp-contract=off, 1 thread, {cpu}"}
 
 
-def same_computation_check(sc, seed, total_steps, gpu_scalars, n=4):
-    """show that the CPU baseline and the GPU run are the same computation.  The first `n` chains of
-    the GPU job are re-run on the oracle with the same key and step count; the hash of the accept/case trace,
-    the state hash and the energy bits must be identical.  Part of the cpu_baseline leg (not timed)."""
+def same_computation_check(scenes, cfg, cpf, seed, total_steps, firsts):
+    """show that the CPU baseline and the GPU run are the same computation, and that a rank's chains
+    are the chains a single-GPU run would have produced.  `firsts` holds, per rank, (global chain id, trace hash)
+    of the rank's first chain; each is re-run on the oracle with the same key and step count on the frame that
+    chain samples, and the hash of its accept / case / state trace must be identical.  Part of the cpu_baseline
+    leg (not timed)."""
     from tests import oracle_lib as O
-    S = sc.n_superpixels
-    fit, valid, _ = O.local_fit(O.moments(sc.disp, sc.label, S), sc.width, sc.height)
-    _, q = O.edge_probs(fit, valid, sc.row_ptr, sc.col)
-    ch = O.Chains(fit, valid, sc.row_ptr, sc.col, q, n, seed, chain_offset=0)
-    ch.run(0, total_steps)
-    o = ch.scalars()
-    ok = all(np.array_equal(np.asarray(gpu_scalars[k][:n]).view(np.uint64) if k == "energy" else gpu_scalars[k][:n],
-                            np.asarray(o[k]).view(np.uint64) if k == "energy" else o[k])
-             for k in ("trace_hash", "state_hash", "energy", "n_accept"))
-    return {"chains": n, "steps_per_chain": int(total_steps), "identical_to_gpu": bool(ok),
-            "trace_hash_chain0": "%016x" % int(o["trace_hash"][0])}
+    tabs = {}
+    ok, rows = True, []
+    for cid, hi, lo in firsts.tolist():
+        sc = scenes[(cid // cpf) % len(scenes)] if cfg == "c5" else scenes[0]
+        if id(sc) not in tabs:
+            S = sc.n_superpixels
+            fit, valid, _ = O.local_fit(O.moments(sc.disp, sc.label, S), sc.width, sc.height)
+            _, q = O.edge_probs(fit, valid, sc.row_ptr, sc.col)
+            tabs[id(sc)] = (fit, valid, q)
+        fit, valid, q = tabs[id(sc)]
+        ch = O.Chains(fit, valid, sc.row_ptr, sc.col, q, 1, seed, chain_offset=int(cid))
+        ch.run(0, total_steps)
+        want = int(ch.scalars()["trace_hash"][0])
+        got = (int(hi) << 32) | int(lo)
+        ok = ok and want == got
+        rows.append({"chain": int(cid), "trace_hash": "%016x" % got})
+    return {"chains": rows, "steps_per_chain": int(total_steps), "identical_to_gpu": bool(ok)}
 
 
 def cpu_baseline_all_cores(sc, seed, seconds, threads):
@@ -135,7 +207,7 @@ def cpu_baseline_all_cores(sc, seed, seconds, threads):
         rate = sum(ex.map(work, range(threads)))       # threads run side by side for the whole window
     return {"value": rate, "unit": "proposals/s", "cores": threads, "kind": "port",
             "sample": f"{threads} host threads side by side for {seconds:.0f} s, each running chains of (1000 burn-in + 10000 "
-                      f"measured) steps of the same C2 scene; sum of the threads' measured rates"}
+                      f"measured) steps of the same C2 scene; sum of the threads' measured rates; {cpu_model()}"}
 
 
 def k1_roofline(host, sc_list, n_frames, reps, device):
@@ -247,7 +319,11 @@ def multiview_line(host, device, n_chains, steps):
 
 
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    plan = launch_plan(a, argv, os.environ)
+    if plan is not None:
+        run_children(*plan)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -263,16 +339,54 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from mcmc_amd import host
+    from mcmc_amd import distributed as D
     from mcmc_amd.scene import make_scene
 
-    sc = make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=a.seed)
+    # ---- the job of this rank: frames resident in HBM, chains by global id --------------------------------
+    cfg = a.config
+    if cfg == "c2":       # weak scaling: every GPU gets a.chains chains of the one C2 frame
+        scenes = [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=a.seed)]
+        frames_local, cpf, chain_off, n_local = 1, a.chains, rank * a.chains, a.chains
+        total_chains, scaling, shared = world * a.chains, "weak", True
+        seed = a.seed
+        workload = ("C2: synthetic 640x480 planar RGB-D scene (seed %d), %d superpixels, %d chains per GPU, step = "
+                    "moments + edge probs + %d sampler iterations/chain"
+                    % (a.seed, scenes[0].n_superpixels, a.chains, a.iters_per_step))
+    elif cfg == "c3":     # strong scaling: 4096 chains of one 1920x1080 frame, contiguous blocks of global ids
+        scenes = [make_scene(width=1920, height=1080, n_planes=24, n_superpixels=4000, seed=2)]
+        chain_off, n_local = D.shard_range(a.total_chains, world, rank)
+        frames_local, cpf, total_chains, scaling, shared = 1, n_local, a.total_chains, "strong", True
+        seed = 2
+        workload = ("C3: synthetic 1920x1080 scene (seed 2), %d superpixels, %d chains sharded over %d GPU(s), step = "
+                    "moments + edge probs + %d sampler iterations/chain"
+                    % (scenes[0].n_superpixels, a.total_chains, world, a.iters_per_step))
+    else:                 # c5, strong scaling: 256 frames x 64 chains, contiguous blocks of frames
+        scenes = [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=100 + i)
+                  for i in range(max(1, a.distinct_scenes))]
+        f_off, frames_local = D.shard_range(a.total_frames, world, rank)
+        cpf = a.chains_per_frame
+        chain_off, n_local = f_off * cpf, frames_local * cpf
+        total_chains, scaling, shared = a.total_frames * cpf, "strong", False
+        seed = 5
+        workload = ("C5: %d frames of 640x480 (%d distinct synthetic scenes, seeds 100.., cycled) x %d chains, frames "
+                    "sharded over %d GPU(s), step = moments + edge probs of the rank's frames + %d sampler "
+                    "iterations/chain" % (a.total_frames, len(scenes), cpf, world, a.iters_per_step))
+    if n_local <= 0:
+        raise SystemExit("bench.py: rank %d has nothing to do (more ranks than units)" % rank)
+    W, H = scenes[0].width, scenes[0].height
+    smax = max(s.n_superpixels for s in scenes); emax = max(s.col.size for s in scenes)
+    sc = scenes[0]
     S = sc.n_superpixels
-    ctx = host.Context(width=640, height=480, device=local)
+    ctx = host.Context(width=W, height=H, device=local, visit_capacity=a.visit_capacity)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.frames_alloc(1, S, sc.col.size)
-    host.load_scene(ctx, 0, sc)
+    ctx.frames_alloc(frames_local, smax, emax)
+    first_frame = (chain_off // cpf) if cfg == "c5" else 0
+    for f in range(frames_local):
+        host.load_scene(ctx, f, scenes[(first_frame + f) % len(scenes)])
     ctx.frames_moments(); ctx.frames_edge_probs()
-    ctx.chains_init(a.chains, seed=a.seed, chain_offset=rank * a.chains)
+    ctx.chains_init(n_local, chains_per_frame=cpf, seed=seed, chain_offset=chain_off)
+    # Statistics keeps every visited state: make room for the whole run now, so no step has to grow the table
+    ctx.reserve_visits((a.warmup + a.steps) * a.iters_per_step)
     ctx.set_timing(True)
 
     def step():
@@ -290,74 +404,104 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    chain_ms = []
     for _ in range(a.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    chain_ms.append(ctx.last_kernel_ms(host.K_CHAIN))
+    k3_ms = ctx.last_kernel_ms(host.K_CHAIN)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # after the timed region: the only exchange of the multi-GPU path, RCCL when N > 1
-    from mcmc_amd import distributed as D
+    # ---- after the timed region: the only exchange of the multi-GPU path, RCCL when N > 1 -----
     sca = ctx.scalars()
-    best_e, best_chain, best_labels, per_rank = D.gather_best(sca["best_energy"], ctx.labels(1, True), rank * a.chains)
-    marg = D.reduce_marginals(ctx.marginals(0), shared_frames=True)
-    n_valid = int((ctx.local_fit(0)[1] != 0).sum())
-    # every valid superpixel is counted once per chain per measured sampler iteration, on every rank
-    assert int(marg.sum()) == world * a.chains * a.iters_per_step * (a.warmup + a.steps) * n_valid
-    assert (sca["status"] == 0).all(), "a chain reported an error status"
     total_steps = (a.warmup + a.steps) * a.iters_per_step
+    assert (sca["status"] == 0).all(), "a chain reported an error status"
     assert (sca["n_case"].sum(axis=1) == total_steps).all()
-    acc_rate = float(sca["n_accept"].sum()) / (a.chains * total_steps)
-    proposals = world * a.chains * a.iters_per_step * a.steps
+    best_e, best_chain, best_labels, per_rank = D.gather_best(sca["best_energy"], ctx.labels(1, True), chain_off)
+    if shared:      # every rank sampled the same frame: all-reduce(sum)
+        marg = D.reduce_marginals(ctx.marginals(0), shared_frames=True)
+        n_valid = int((ctx.local_fit(0)[1] != 0).sum())
+        # every valid superpixel is counted once per chain per measured sampler iteration, on every rank
+        assert int(marg.sum()) == total_chains * total_steps * n_valid
+        frames_gathered = 1
+    else:           # disjoint frames: all-gather, rank blocks in frame order (equal shares required)
+        mine = np.stack([ctx.marginals(f) for f in range(frames_local)])
+        if a.total_frames % world == 0:
+            marg = D.reduce_marginals(mine, shared_frames=False)
+            frames_gathered = int(marg.shape[0])
+            assert frames_gathered == a.total_frames
+            per_frame = marg.reshape(a.total_frames, -1).sum(axis=1)
+            nv = [int((ctx.local_fit(f)[1] != 0).sum()) for f in range(frames_local)]
+            assert all(int(per_frame[first_frame + f]) == cpf * total_steps * nv[f] for f in range(frames_local))
+        else:
+            marg, frames_gathered = mine, frames_local
+    # one chain per rank (its first): the trace hash a single-GPU run gives the same global chain id is
+    # recomputed on the oracle in the cpu_baseline leg below
+    first = np.array([chain_off, int(sca["trace_hash"][0]) >> 32, int(sca["trace_hash"][0]) & 0xFFFFFFFF], np.int64)
+    firsts = D.gather_rows(first)
+    overflow = D.sum_max(np.array([int(sca["overflow"].sum())], np.int64), np.array([int(sca["overflow"].max())], np.int64))
+    acc_rate = float(sca["n_accept"].sum()) / (n_local * total_steps)
+    proposals = total_chains * a.iters_per_step * a.steps
     out = {
         "metric": "MCMC proposals evaluated/sec (whole node) at 640x480 RGB-D; % HBM peak",
         "value": proposals / dt, "unit": "proposals/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "C2: synthetic 640x480 planar RGB-D scene (seed %d), %d superpixels, "
-                               "%d chains per GPU, step = moments + edge probs + %d sampler iterations/chain"
-                               % (a.seed, S, a.chains, a.iters_per_step),
-                   "chains_per_gpu": a.chains, "iters_per_step": a.iters_per_step, "superpixels": S,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "name": cfg,
+                   "chains_per_gpu": n_local, "chains_total": total_chains, "frames_per_gpu": frames_local,
+                   "iters_per_step": a.iters_per_step, "superpixels": S,
                    "directed_edges": int(sc.col.size), "accept_rate": acc_rate,
-                   "segments_mean": float(np.mean([len(np.unique(l[:S])) for l in ctx.labels(0, True)[:64]])),
-                   "best_energy": best_e, "best_chain": best_chain, "ranks_gathered": len(per_rank)},
+                   "segments_mean": float(np.mean([len(np.unique(l[:S])) for l in ctx.labels(0, True)[:min(64, cpf)]])),
+                   "best_energy": best_e, "best_chain": best_chain, "ranks_gathered": len(per_rank),
+                   "marginal_frames_gathered": frames_gathered,
+                   "chain_kernel_variant": ctx.last_variant()},
+        "statistics": {"visit_capacity": ctx.visit_capacity(), "overflow_sum": int(overflow[0]), "overflow_max": int(overflow[1]),
+                       "measured_steps_per_chain": int(total_steps),
+                       "note": "Statistics::update visits that found the per-chain visit table full; 0 = every state counted"},
     }
     if rank == 0:
-        k3_ms = chain_ms[-1]
         out["chain_kernel"] = {"kernel": "chain_run_kernel", "ms_per_launch": k3_ms,
-                               "proposals_per_launch": a.chains * a.iters_per_step,
+                               "proposals_per_launch": n_local * a.iters_per_step,
                                "us_per_proposal_per_chain": k3_ms * 1e3 / a.iters_per_step,
                                "bound": "latency (LDS-resident BFS); not an HBM claim"}
-        out["frame_kernels_ms"] = {"sp_moments_1frame": ctx.last_kernel_ms(host.K_MOMENTS),
+        out["frame_kernels_ms"] = {"sp_moments": ctx.last_kernel_ms(host.K_MOMENTS),
                                    "local_fit": ctx.last_kernel_ms(host.K_LOCAL_FIT),
                                    "edge_prob": ctx.last_kernel_ms(host.K_EDGE_PROB)}
     ctx.close()
-    if rank == 0 and world == 1 and not a.no_multiview:
-        out["multiview"] = multiview_line(host, local, a.mv_chains, a.mv_steps)
-    if rank == 0 and world == 1:
-        scs = None
-        if not a.no_roofline or not a.no_c5:
-            scs = [sc] + [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=100 + i)
-                          for i in range(3)]
-        if not a.no_c5:
-            out["c5_share"] = c5_share_line(host, scs, local)
-        if not a.no_roofline:
-            out["roofline"] = k1_roofline(host, scs, a.roofline_frames, a.roofline_reps, local)
-        if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, a.seed, a.cpu_seconds)
-            out["cpu_baseline"]["same_computation"] = same_computation_check(sc, a.seed, total_steps, sca)
-            assert out["cpu_baseline"]["same_computation"]["identical_to_gpu"], "GPU chains differ from the oracle"
-            nthr = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(sc, a.seed, min(a.cpu_seconds, 6.0), min(nthr, 16))
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()      # nothing below communicates; the other ranks are done
+    if rank == 0 and world == 1 and cfg == "c2" and not a.no_multiview:
+        out["multiview"] = multiview_line(host, local, a.mv_chains, a.mv_steps)
+    if rank == 0:
+        c2s = scenes if cfg != "c3" else []
+        if (not a.no_roofline or (world == 1 and cfg == "c2" and not a.no_c5)) and len(c2s) < 4:
+            c2s = c2s + [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=100 + i)
+                         for i in range(4 - len(c2s))]
+        if world == 1 and cfg == "c2" and not a.no_c5:
+            out["c5_share"] = c5_share_line(host, c2s, local)
+        if not a.no_roofline:
+            out["roofline"] = k1_roofline(host, c2s, a.roofline_frames, a.roofline_reps, local)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, seed, a.cpu_seconds)
+        if not a.no_cpu_baseline:
+            # the CPU baseline and the GPU figure are the same computation -- the first chain of
+            # every rank re-run on the oracle with the same global id (what a single-GPU run would give it)
+            chk = same_computation_check(scenes, cfg, cpf, seed, total_steps, firsts)
+            if world == 1:
+                out["cpu_baseline"]["same_computation"] = chk
+            else:
+                out["cross_rank_check"] = chk
+            assert chk["identical_to_gpu"], "GPU chains differ from the oracle"
+        if world == 1 and cfg == "c2" and not a.no_cpu_baseline:
+            ncpu = os.cpu_count() or 1
+            # the box's CPU share is what OMP_NUM_THREADS says (16 per GPU there); without it, every CPU up to 64
+            nthr = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or min(ncpu, 64), ncpu))
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(sc, seed, min(a.cpu_seconds, 6.0), nthr)
+            out["cpu_baseline_all_cores"]["host_cpus"] = ncpu
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

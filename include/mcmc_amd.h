@@ -34,9 +34,11 @@ extern "C" {
 #define MCMC_E_TOO_LARGE (-6)    /* superpixel count beyond what the chain kernel's LDS state holds */
 #define MCMC_E_NOSUPERPIXELS (-7)/* frame has no superpixel that passes the A1 filter */
 #define MCMC_E_RANGE (-8)        /* "Weird channel value." OverSegmentation.cpp:382 */
+#define MCMC_E_OVERFLOW (-9)     /* a caller-fixed visit table filled up: Statistics results may be incomplete */
 
 #define MCMC_NOLABEL 0xFFFFu     /* pixel / superpixel that belongs to no superpixel / segment */
 #define MCMC_MOMENT_STRIDE 10    /* N Su Sv Suu Suv Svv Sb Sub Svb Sbb (int64) */
+#define MCMC_MAX_DEGREE 32760    /* neighbours of one superpixel (12-bit part index x 8 in the growth FIFO) */
 #define MCMC_FIT_STRIDE 16       /* Suu Suv Svv Su Sv N | Sub Svb Sb | theta_a theta_b theta_c | Sbb ssr 0 0 (f64, centred) */
 
 typedef struct mcmc_ctx mcmc_ctx;
@@ -49,7 +51,9 @@ typedef struct mcmc_params {
     double disparity_variance;   /* kDisparityVariance = 7 */
     double new_segment_prob;     /* newSegmentProb = 0.8 */
     int32_t marginal_bins;       /* Lmax of the label-marginal histogram (build's choice, 64) */
-    int32_t visit_capacity;      /* distinct states counted per chain before overflow (256) */
+    int32_t visit_capacity;      /* Statistics::entries_ (Statistics.h:30): 0 = sized from the run, every visited
+                                  * state is kept, as in the reference (default); > 0 = fixed number of slots per
+                                  * chain, visits of further states are counted in `overflow` */
 } mcmc_params;
 
 void mcmc_default_params(mcmc_params *p);
@@ -78,8 +82,9 @@ int mcmc_frame_upload(mcmc_ctx *ctx, int frame, const int16_t *disp, const uint1
 /* Same, from device memory already resident in HBM (device-to-device copy). */
 int mcmc_frame_upload_device(mcmc_ctx *ctx, int frame, const void *d_disp, const void *d_label,
                              int n_superpixels);
-/* Adjacency in CSR form, neighbours ascending by id: SuperPixel::neighbors_
- * keys (include/MyMath.h:181; filled at OverSegmentation.cpp:186-190). */
+/* Adjacency in CSR form, neighbours strictly ascending by id (no duplicates): SuperPixel::neighbors_
+ * keys (include/MyMath.h:181; filled at OverSegmentation.cpp:186-190).  MCMC_E_BADARG for a malformed CSR,
+ * MCMC_E_TOO_LARGE for a superpixel with more than MCMC_MAX_DEGREE neighbours. */
 int mcmc_frame_set_graph(mcmc_ctx *ctx, int frame, const uint32_t *row_ptr, const uint32_t *col,
                          uint32_t e2);
 
@@ -133,15 +138,27 @@ int mcmc_chains_get_trace(mcmc_ctx *ctx, uint8_t *out /* n_chains*steps of last 
 /* which: 0 current state, 1 best-energy state, 2 most-visited state
  * (printResults uses the most visited, src/exe/can05_sampler.cpp:36).
  * canonical != 0: first-appearance relabel of Segmentation::computeHash
- * (Segmentation.cpp:197-233); else the smallest member id of each segment. */
+ * (Segmentation.cpp:197-233); else the smallest member id of each segment.
+ * which = 2 returns MCMC_E_OVERFLOW (labels still written) if a caller-fixed visit table filled up. */
 int mcmc_chains_get_labels(mcmc_ctx *ctx, int which, int canonical, uint16_t *out /* n_chains*s_max */);
 /* Any pointer may be NULL.  n_case: 3 per chain.  status: per-chain MCMC_E_*. */
 int mcmc_chains_get_scalars(mcmc_ctx *ctx, double *energy, double *best_energy, uint64_t *state_hash,
                             uint64_t *trace_hash, uint64_t *n_accept, uint64_t *n_case,
                             int32_t *status, uint64_t *top_count, uint64_t *top_hash,
                             uint64_t *overflow);
-/* Statistics::entries_ per chain: visit_capacity (hash, count) slots, hash 0 count 0 = empty. */
+/* Statistics::entries_ per chain (Statistics.h:30-47): mcmc_chains_visit_capacity() (hash, count) slots, count 0 =
+ * empty.  Statistics::getOrderedStates (Statistics.h:50-70) = these entries sorted by count, descending;
+ * Statistics::getCount(state) (:73-83) = the count stored with the state's hash. */
 int mcmc_chains_get_visits(mcmc_ctx *ctx, uint64_t *hash, uint64_t *count);
+/* Slots per chain of the visit table right now (it grows with the run when params.visit_capacity == 0). */
+int mcmc_chains_visit_capacity(const mcmc_ctx *ctx);
+/* Optional: make room now for `measured_steps` further Statistics::update calls per chain, so that no later
+ * mcmc_chains_run has to grow the table (growing allocates and re-inserts). */
+int mcmc_chains_reserve_visits(mcmc_ctx *ctx, uint64_t measured_steps);
+/* The out-parameters of Problem::propose for the last step each chain took (Problem.cpp:116,213-217;
+ * MCMC.h:214-219): targetRatio (log domain, the literal 1.0 of case A included) and proposalRatio (linear).
+ * Either pointer may be NULL; n_chains values each. */
+int mcmc_chains_get_last_ratios(mcmc_ctx *ctx, double *targetL, double *proposal);
 /* Label marginals of one frame summed over its chains: s_max*marginal_bins counts. */
 int mcmc_frame_get_marginals(mcmc_ctx *ctx, int frame, uint64_t *out);
 /* Segmentation::computeProbability (Segmentation.cpp:185-195) recomputed from the segment cache. */

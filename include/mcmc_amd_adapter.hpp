@@ -14,6 +14,7 @@
 #ifndef MCMC_AMD_ADAPTER_HPP
 #define MCMC_AMD_ADAPTER_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <limits>
@@ -105,14 +106,32 @@ public:
         return r;
     }
     // Statistics::entries_ of one chain (Statistics.h:30): state hash -> visit count
-    std::map<uint64_t, uint64_t> visits(int chain, int capacity = 256)
+    std::map<uint64_t, uint64_t> visits(int chain)
     {
+        const int capacity = mcmc_chains_visit_capacity(ctx_);
+        if (capacity <= 0 || chain < 0 || chain >= n_) throw std::runtime_error("mcmc_amd: visits: no chains / bad chain");
         std::vector<uint64_t> h((size_t)n_ * capacity), c((size_t)n_ * capacity);
         ck(mcmc_chains_get_visits(ctx_, h.data(), c.data()));
         std::map<uint64_t, uint64_t> m;
         for (int i = 0; i < capacity; ++i)
             if (c[(size_t)chain * capacity + i]) m[h[(size_t)chain * capacity + i]] = c[(size_t)chain * capacity + i];
         return m;
+    }
+    // Statistics::getOrderedStates (Statistics.h:50-70): (count, state hash) of one chain, most visited first
+    std::vector<std::pair<uint64_t, uint64_t>> ordered_states(int chain)
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> v;
+        for (const auto& kv : visits(chain)) v.emplace_back(kv.second, kv.first);
+        std::sort(v.begin(), v.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) {
+            return a.first != b.first ? a.first > b.first : a.second < b.second;
+        });
+        return v;
+    }
+    // Problem::propose's out-parameters for the last step of every chain (Problem.cpp:213-217)
+    void last_ratios(std::vector<double>& targetL, std::vector<double>& proposal)
+    {
+        targetL.resize((size_t)n_); proposal.resize((size_t)n_);
+        ck(mcmc_chains_get_last_ratios(ctx_, targetL.data(), proposal.data()));
     }
     // Segment(superPixels).probabilityL_ (Graph.h:33-40)
     double segment_probability(const std::vector<uint32_t>& members)
@@ -137,7 +156,7 @@ private:
 // State is a view of the one device-resident chain; hash_ is what Statistics keys on
 // (Statistics.h:37).
 struct State {
-    long hash_ = 0;
+    mutable long hash_ = 0;   // always the device chain's current hash, whichever State object the caller keeps
     Sampler* sampler = nullptr;
     bool accepted = true;
 };
@@ -165,9 +184,12 @@ struct Problem {
         return st;
     }
 
-    // Problem::propose(state, targetRatio (log), proposalRatio) (Problem.cpp:116-224).  The
-    // device takes the accept decision itself; the ratios returned make
-    // FastMetropolisHastings::iterate (MCMC.h:218-227) reach the same decision.
+    // Problem::propose(state, targetRatio (log), proposalRatio) (Problem.cpp:116-224).  The ratios are the real
+    // ones of the step (Problem.cpp:213-217).  The chain lives on the device, which has already taken the accept
+    // decision with its own Philox draw (the reference's iterate draws rand(), MCMC.h:223); every State is a view
+    // of that one chain, so both the State passed in and the one returned carry the chain's hash after the step,
+    // and whichever of the two FastMetropolisHastings::iterate keeps (MCMC.h:224-237), Statistics::update
+    // (Statistics.h:37) books the state the chain is really in.  `accepted` tells what the device decided.
     static State* propose(const State& state, long double& targetRatio, long double& proposalRatio)
     {
         Sampler* s = state.sampler;
@@ -180,9 +202,11 @@ struct Problem {
         next->sampler = s;
         next->hash_ = (long)sc.state_hash[0];
         next->accepted = sc.n_accept[0] != before;
-        proposalRatio = 1.0L;
-        targetRatio = next->accepted ? std::numeric_limits<long double>::infinity()
-                                     : -std::numeric_limits<long double>::infinity();
+        std::vector<double> t, p;
+        s->last_ratios(t, p);
+        targetRatio = (long double)t[0];
+        proposalRatio = (long double)p[0];
+        state.hash_ = next->hash_;
         return next;
     }
 };

@@ -49,7 +49,13 @@ struct Chains {
     uint8_t* trace = nullptr;
     unsigned long long trace_cap = 0, last_steps = 0;
     unsigned long long* slots_g = nullptr; size_t slots_cap = 0;
+    double *last_targetL = nullptr, *last_prop = nullptr;
+    int hcap = 0;                          // slots per chain of the visit table (grows when visit_capacity == 0)
+    unsigned long long measured = 0;       // Statistics::update calls made so far per chain (steps after burn-in)
 };
+
+constexpr int kVisitCapAuto0 = 256;        // first size of an automatically sized visit table
+constexpr int kVisitCapMax = 1 << 22;      // 4 Mi slots (64 MB) per chain: beyond this visits count as overflow
 
 }  // namespace
 
@@ -116,7 +122,7 @@ void free_chains(Chains& h)
     dfree(h.segC); dfree(h.energy); dfree(h.best_energy); dfree(h.tmp_energy);
     dfree(h.state_hash); dfree(h.trace_hash); dfree(h.n_accept); dfree(h.n_case);
     dfree(h.visit_hash); dfree(h.visit_count); dfree(h.overflow); dfree(h.top_count); dfree(h.top_hash);
-    dfree(h.status); dfree(h.trace); dfree(h.slots_g);
+    dfree(h.status); dfree(h.trace); dfree(h.slots_g); dfree(h.last_targetL); dfree(h.last_prop);
     h = Chains();
 }
 
@@ -150,9 +156,35 @@ ChainArgs chain_args(mcmc_ctx* c)
     a.n_accept = c->ch.n_accept; a.n_case = c->ch.n_case; a.status = c->ch.status;
     a.visit_hash = c->ch.visit_hash; a.visit_count = c->ch.visit_count;
     a.overflow = c->ch.overflow; a.top_count = c->ch.top_count; a.top_hash = c->ch.top_hash;
+    a.last_targetL = c->ch.last_targetL; a.last_prop = c->ch.last_prop;
     a.marg = c->d_marg; a.trace = nullptr; a.trace_stride = 0;
-    a.hcap = c->p.visit_capacity; a.lmax = c->p.marginal_bins;
+    a.hcap = c->ch.hcap; a.lmax = c->p.marginal_bins;
     return a;
+}
+
+// Statistics keeps every visited state (Statistics.h:30-47).  With visit_capacity == 0 the per-chain table is
+// sized from the run: room for twice the Statistics::update calls made so far plus those about to be made (a
+// chain visits at most one new state per step), so it never fills.  Growing re-inserts the old entries.
+int ensure_visit_capacity(mcmc_ctx* c, unsigned long long measured_total)
+{
+    Chains& h = c->ch;
+    if (c->p.visit_capacity > 0) return MCMC_OK;          // fixed by the caller: overflow is counted, not avoided
+    unsigned long long want = 2ull * (measured_total + 1ull);
+    if (want > (unsigned long long)kVisitCapMax) want = (unsigned long long)kVisitCapMax;
+    if ((unsigned long long)h.hcap >= want) return MCMC_OK;
+    int ncap = h.hcap;
+    while ((unsigned long long)ncap < want) ncap *= 2;
+    const size_t NH = (size_t)h.n * (size_t)ncap;
+    unsigned long long *nh = nullptr, *nc = nullptr;
+    HIPCHK(c, dalloc(&nh, NH));
+    if (dalloc(&nc, NH) != hipSuccess) { dfree(nh); return fail(c, MCMC_E_DEVICE, "visit table: out of device memory"); }
+    HIPCHK(c, hipMemsetAsync(nc, 0, NH * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(nh, 0, NH * 8, c->stream));
+    HIPCHK(c, launch_visit_rehash(h.visit_hash, h.visit_count, h.hcap, nh, nc, ncap, h.n, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(h.visit_hash); dfree(h.visit_count);
+    h.visit_hash = nh; h.visit_count = nc; h.hcap = ncap;
+    return MCMC_OK;
 }
 
 }  // namespace
@@ -168,7 +200,7 @@ void mcmc_default_params(mcmc_params* p)
     p->disparity_variance = 7.0;
     p->new_segment_prob = 0.8;
     p->marginal_bins = 64;
-    p->visit_capacity = 256;
+    p->visit_capacity = 0;   /* sized from the run, never fills */
 }
 
 int mcmc_ctx_create(int device, const mcmc_params* params, mcmc_ctx** out)
@@ -178,7 +210,7 @@ int mcmc_ctx_create(int device, const mcmc_params* params, mcmc_ctx** out)
     mcmc_params p;
     if (params) p = *params; else mcmc_default_params(&p);
     if (p.width <= 0 || p.height <= 0 || p.width > 4096 || p.height > 4096 || !(p.disparity_variance > 0.0) ||
-        !(p.new_segment_prob >= 0.0 && p.new_segment_prob <= 1.0) || p.marginal_bins < 1 || p.visit_capacity < 1)
+        !(p.new_segment_prob >= 0.0 && p.new_segment_prob <= 1.0) || p.marginal_bins < 1 || p.visit_capacity < 0)
         return MCMC_E_BADARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return MCMC_E_DEVICE;
@@ -329,14 +361,22 @@ int mcmc_frame_upload_device(mcmc_ctx* c, int frame, const void* d_disp, const v
 
 int mcmc_frame_set_graph(mcmc_ctx* c, int frame, const uint32_t* row_ptr, const uint32_t* col, uint32_t e2)
 {
-    if (!frame_ok(c, frame) || !row_ptr || (!col && e2) || (int)e2 > c->e2_max) return fail(c, MCMC_E_BADARG, "frame_set_graph: bad argument");
+    if (!frame_ok(c, frame) || !row_ptr || (!col && e2) || e2 > (uint32_t)c->e2_max) return fail(c, MCMC_E_BADARG, "frame_set_graph: bad argument");
     const int S = c->h_S[frame];
     if (S <= 0) return fail(c, MCMC_E_STATE, "frame_set_graph: upload the frame first");
     if (row_ptr[0] != 0 || row_ptr[S] != e2) return fail(c, MCMC_E_BADARG, "frame_set_graph: row_ptr does not span e2");
+    for (int i = 0; i < S; ++i) {
+        if (row_ptr[i + 1] < row_ptr[i] || row_ptr[i + 1] > e2) return fail(c, MCMC_E_BADARG, "frame_set_graph: row_ptr not monotone");
+        // the growth FIFO addresses a superpixel's neighbours in parts of 8 with a 12-bit part index
+        if (row_ptr[i + 1] - row_ptr[i] > (uint32_t)MCMC_MAX_DEGREE) return fail(c, MCMC_E_TOO_LARGE, "frame_set_graph: a superpixel has more than MCMC_MAX_DEGREE neighbours");
+    }
+    // neighbours strictly ascending within a row: SuperPixel::neighbors_ is a map keyed by the neighbour, so no
+    // neighbour appears twice (MyMath.h:181); a duplicate entry would be tried and counted twice here
     for (int i = 0; i < S; ++i)
-        if (row_ptr[i + 1] < row_ptr[i]) return fail(c, MCMC_E_BADARG, "frame_set_graph: row_ptr not monotone");
-    for (uint32_t e = 0; e < e2; ++e)
-        if (col[e] >= (uint32_t)S) return fail(c, MCMC_E_BADARG, "frame_set_graph: neighbour id out of range");
+        for (uint32_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+            if (col[e] >= (uint32_t)S) return fail(c, MCMC_E_BADARG, "frame_set_graph: neighbour id out of range");
+            if (e > row_ptr[i] && col[e] <= col[e - 1]) return fail(c, MCMC_E_BADARG, "frame_set_graph: neighbours of a superpixel must be strictly ascending (no duplicates)");
+        }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->d_rowp + (size_t)frame * (c->s_max + 1), row_ptr, ((size_t)S + 1) * 4, hipMemcpyHostToDevice, c->stream));
     if (e2) HIPCHK(c, hipMemcpyAsync(c->d_col + (size_t)frame * c->e2_max, col, (size_t)e2 * 4, hipMemcpyHostToDevice, c->stream));
@@ -428,6 +468,8 @@ int mcmc_frames_edge_probs(mcmc_ctx* c, int first, int count)
     a.fit = c->d_fit; a.valid = c->d_valid; a.rowp = c->d_rowp; a.col = c->d_col; a.S = c->d_S; a.E2 = c->d_E2;
     a.q = c->d_q; a.status = c->d_fstatus; a.var = c->p.disparity_variance;
     a.s_max = c->s_max; a.e2_max = c->e2_max; a.first_frame = first;
+    // the kernel only ever sets bits: a frame re-uploaded with good data must not keep an old NaN / inf flag
+    HIPCHK(c, hipMemsetAsync(c->d_fstatus + first, 0, (size_t)count * sizeof(int), c->stream));
     {
         Timer t(c, K_EDGE);
         HIPCHK(c, launch_edge_prob(a, count, c->stream));
@@ -550,7 +592,9 @@ int mcmc_chains_init(mcmc_ctx* c, int n_chains, int cpf, uint32_t seed, uint32_t
     free_chains(c->ch);
     Chains& h = c->ch;
     h.n = n_chains; h.cpf = cpf; h.seed = seed; h.offset = chain_offset; h.step = 0;
-    const size_t N = (size_t)n_chains, NS = N * (size_t)c->s_max, NH = N * (size_t)c->p.visit_capacity;
+    h.hcap = c->p.visit_capacity > 0 ? c->p.visit_capacity : kVisitCapAuto0;
+    h.measured = 0;
+    const size_t N = (size_t)n_chains, NS = N * (size_t)c->s_max, NH = N * (size_t)h.hcap;
     HIPCHK(c, dalloc(&h.label, NS)); HIPCHK(c, dalloc(&h.best_label, NS));
     HIPCHK(c, dalloc(&h.top_label, NS)); HIPCHK(c, dalloc(&h.canon, NS)); HIPCHK(c, dalloc(&h.segC, NS * mc::kSegCacheStride));
     HIPCHK(c, dalloc(&h.energy, N)); HIPCHK(c, dalloc(&h.best_energy, N)); HIPCHK(c, dalloc(&h.tmp_energy, N));
@@ -558,6 +602,7 @@ int mcmc_chains_init(mcmc_ctx* c, int n_chains, int cpf, uint32_t seed, uint32_t
     HIPCHK(c, dalloc(&h.n_case, N * 3)); HIPCHK(c, dalloc(&h.visit_hash, NH)); HIPCHK(c, dalloc(&h.visit_count, NH));
     HIPCHK(c, dalloc(&h.overflow, N)); HIPCHK(c, dalloc(&h.top_count, N)); HIPCHK(c, dalloc(&h.top_hash, N));
     HIPCHK(c, dalloc(&h.status, N));
+    HIPCHK(c, dalloc(&h.last_targetL, N)); HIPCHK(c, dalloc(&h.last_prop, N));
     HIPCHK(c, hipMemsetAsync(c->d_marg, 0, (size_t)c->n_frames * c->s_max * (size_t)c->p.marginal_bins * 8, c->stream));
     ChainArgs a = chain_args(c);
     HIPCHK(c, launch_chain_init(a, c->stream));
@@ -587,6 +632,7 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
     if (!c || c->ch.n == 0) return fail(c, MCMC_E_STATE, "chains_run: chains_init first");
     HIPCHK(c, hipSetDevice(c->device));
     Chains& h = c->ch;
+    { const int rc = ensure_visit_capacity(c, h.measured + iters); if (rc != MCMC_OK) return rc; }
     ChainArgs a = chain_args(c);
     a.step0 = h.step; a.burn_in = burn_in; a.iters = iters;
     const unsigned long long total = burn_in + iters;
@@ -615,7 +661,30 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
         if (e == hipErrorInvalidValue) return fail(c, MCMC_E_TOO_LARGE, "chains_run: per-chain state does not fit 160 KB of LDS");
         HIPCHK(c, e);
     }
-    h.step += total; h.last_steps = total;
+    h.step += total; h.last_steps = total; h.measured += iters;
+    return MCMC_OK;
+}
+
+int mcmc_chains_reserve_visits(mcmc_ctx* c, uint64_t measured_steps)
+{
+    if (!c || c->ch.n == 0) return fail(c, MCMC_E_STATE, "chains_reserve_visits: chains_init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return ensure_visit_capacity(c, c->ch.measured + measured_steps);
+}
+
+int mcmc_chains_visit_capacity(const mcmc_ctx* c)
+{
+    return c ? c->ch.hcap : MCMC_E_BADARG;
+}
+
+int mcmc_chains_get_last_ratios(mcmc_ctx* c, double* targetL, double* proposal)
+{
+    if (!c || c->ch.n == 0) return fail(c, MCMC_E_STATE, "chains_get_last_ratios: no chains");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->ch.n;
+    if (targetL) HIPCHK(c, hipMemcpyAsync(targetL, c->ch.last_targetL, N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (proposal) HIPCHK(c, hipMemcpyAsync(proposal, c->ch.last_prop, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCMC_OK;
 }
 
@@ -654,7 +723,16 @@ int mcmc_chains_get_labels(mcmc_ctx* c, int which, int canonical, uint16_t* out)
         src = h.canon;
     }
     HIPCHK(c, hipMemcpyAsync(out, src, (size_t)h.n * c->s_max * 2, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> ovf;
+    if (which == 2) {
+        ovf.resize((size_t)h.n);
+        HIPCHK(c, hipMemcpyAsync(ovf.data(), h.overflow, (size_t)h.n * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // a full visit table stops counting new states: "most visited" may then be wrong.  The labels are still
+    // written; the status says so (only possible with a caller-fixed visit_capacity).
+    for (unsigned long long o : ovf)
+        if (o) return fail(c, MCMC_E_OVERFLOW, "chains_get_labels: a chain's visit table overflowed (visit_capacity too small); the most-visited state may be wrong");
     return MCMC_OK;
 }
 
@@ -683,7 +761,7 @@ int mcmc_chains_get_visits(mcmc_ctx* c, uint64_t* hash, uint64_t* count)
     if (!c || !hash || !count) return fail(c, MCMC_E_BADARG, "chains_get_visits: bad argument");
     if (c->ch.n == 0) return fail(c, MCMC_E_STATE, "chains_get_visits: no chains");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t NH = (size_t)c->ch.n * (size_t)c->p.visit_capacity;
+    const size_t NH = (size_t)c->ch.n * (size_t)c->ch.hcap;
     HIPCHK(c, hipMemcpyAsync(hash, c->ch.visit_hash, NH * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(count, c->ch.visit_count, NH * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -201,6 +201,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     } while (0)
 
 constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
+constexpr uint32_t kPartShift = 20u;       // FIFO slot word: node (16) | entries (4) | part (12)
 
 template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF, bool TOPO_LDS = false>
 __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     // ---- wave-private state ----
     unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
     uint16_t* label = reinterpret_cast<uint16_t*>(wbase + L.w_label);
-    // FIFO of the growth: .x = node | entries << 16 | part << 24, .y = first CSR entry of the part
+    // FIFO of the growth: .x = node | entries << 16 (0..8, 4 bits) | part << 20 (12 bits: a node of up to
+    // kMaxDegree neighbours), .y = first CSR entry of the part
     uint2* slots = TAB_LDS ? reinterpret_cast<uint2*>(wbase + L.w_slots)
                            : reinterpret_cast<uint2*>(a.slots_g) + (size_t)chain * queue_slots(s_lds, e2_lds);
     // appends to the FIFO are read by other lanes of this wave in a later pass
@@ -309,6 +311,9 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     int status = a.status[chain];
     uint64_t top_count = a.top_count[chain], top_hash = a.top_hash[chain], overflow = a.overflow[chain];
     uint64_t dwell = 0;
+    // targetRatio (log) and proposalRatio of the last step taken, as Problem::propose hands them to its caller
+    // (Problem.cpp:213-217; MCMC.h:214-219)
+    double last_targetL = a.last_targetL[chain], last_prop = a.last_prop[chain];
 
     const double var = a.var, nsp = a.new_seg_prob;
     const double log_var = det_log(var);
@@ -326,28 +331,39 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     // split/merge, so visits are booked when the chain leaves a state.
     auto flush_stats = [&]() {
         if (dwell == 0) return;
-        // visit table: open addressing, count == 0 marks an empty slot
+        // visit table (Statistics::entries_, Statistics.h:30-47): open addressing with linear probing, count == 0
+        // marks an empty slot.  64 slots per trip, one per lane; the first slot in probe order that holds this
+        // state or is empty takes the visits.
         uint64_t cnt = 0;
         int snap = 0;
-        if (lane == 0) {
-            const uint32_t h0 = (uint32_t)(state_hash % (uint64_t)a.hcap);
+        {
+            const uint32_t hcap = (uint32_t)a.hcap;
+            const uint32_t h0 = (uint32_t)(state_hash % (uint64_t)hcap);
             bool done = false;
-            for (int p = 0; p < a.hcap && !done; ++p) {
-                const uint32_t idx = (h0 + (uint32_t)p) % (uint32_t)a.hcap;
-                const uint64_t c = vc[idx];
-                if (c == 0) { vh[idx] = state_hash; vc[idx] = dwell; cnt = dwell; done = true; }
-                else if (vh[idx] == state_hash) { cnt = c + dwell; vc[idx] = cnt; done = true; }
+            for (uint32_t p0 = 0; p0 < hcap && !done; p0 += kWave) {
+                const uint32_t p = p0 + (uint32_t)lane;
+                uint32_t idx = h0 + p;
+                if (idx >= hcap) idx -= hcap;
+                const bool in = p < hcap;
+                const uint64_t c = in ? vc[idx] : 0ull;
+                const uint64_t hh = in ? vh[idx] : 0ull;
+                const uint64_t m = __ballot(in && (c == 0ull || hh == state_hash));
+                if (m) {
+                    const int w = __ffsll((unsigned long long)m) - 1;
+                    uint64_t nc = c + dwell;
+                    if (lane == w) { if (c == 0ull) vh[idx] = state_hash; vc[idx] = nc; }
+                    cnt = (uint64_t)__shfl((unsigned long long)nc, w, kWave);
+                    done = true;
+                }
             }
+            // the slot is read back by other lanes of this wave at a later flush (same CU, same L1)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             if (!done) overflow += dwell;
             else if (cnt > top_count || (cnt == top_count && state_hash < top_hash)) {
                 snap = (state_hash != top_hash || top_count == 0) ? 1 : 0;
                 top_count = cnt; top_hash = state_hash;
             }
         }
-        snap = uni(snap);
-        top_count = (uint64_t)__shfl((unsigned long long)top_count, 0, kWave);
-        top_hash = (uint64_t)__shfl((unsigned long long)top_hash, 0, kWave);
-        overflow = (uint64_t)__shfl((unsigned long long)overflow, 0, kWave);
         if (snap) {
             uint16_t* tl = a.top_label + (size_t)chain * a.s_max;
             for (int i = lane; i < S; i += kWave) tl[i] = label[i];
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 const uint32_t rs0 = rowp[start], d0 = rowp[start + 1] - rs0;
                 const uint32_t parts0 = d0 <= 8u ? 1u : (d0 + 7u) >> 3;
                 for (uint32_t pp = (uint32_t)lane; pp < parts0; pp += kWave)
-                    slots[pp] = make_uint2(start | (min(8u, d0 - 8u * pp) << 16) | (pp << 24), rs0 + 8u * pp);
+                    slots[pp] = make_uint2(start | (min(8u, d0 - 8u * pp) << 16) | (pp << kPartShift), rs0 + 8u * pp);
                 if (lane == 0) cl[start] = 0u;
                 qt = parts0;
                 queue_fence();
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     const uint2 entA = slots[head + g8];
                     uint2 entB = make_uint2(0u, 0u);
                     if (8u + g8 < K2) entB = slots[head + 8u + g8];
-                    const bool actA = s8 < ((entA.x >> 16) & 0xFFu), actB = s8 < ((entB.x >> 16) & 0xFFu);
+                    const bool actA = s8 < ((entA.x >> 16) & 0xFu), actB = s8 < ((entB.x >> 16) & 0xFu);
                     const uint32_t eA = actA ? entA.y + s8 : 0u, eB = actB ? entB.y + s8 : 0u;
                     const double rA = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
                     const double rB = rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), lane);
@@ -462,9 +478,9 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                             const uint32_t baseA = qt + (uint32_t)mbcnt(wmA) + (uint32_t)mbcnt(bmA);
                             const uint32_t baseB = qt + tA + (uint32_t)mbcnt(wmB) + (uint32_t)mbcnt(bmB);
                             if (winA) slots[baseA] = make_uint2(jA | (min(8u, djA) << 16), rjA);
-                            if (bigA) slots[baseA + 1u] = make_uint2(jA | ((djA - 8u) << 16) | (1u << 24), rjA + 8u);
+                            if (bigA) slots[baseA + 1u] = make_uint2(jA | ((djA - 8u) << 16) | (1u << kPartShift), rjA + 8u);
                             if (winB) slots[baseB] = make_uint2(jB | (min(8u, djB) << 16), rjB);
-                            if (bigB) slots[baseB + 1u] = make_uint2(jB | ((djB - 8u) << 16) | (1u << 24), rjB + 8u);
+                            if (bigB) slots[baseB + 1u] = make_uint2(jB | ((djB - 8u) << 16) | (1u << kPartShift), rjB + 8u);
                             qt += tA + nB + (uint32_t)__popcll((unsigned long long)bmB);
                         } else {
                             const uint32_t partsA = winA ? (djA <= 8u ? 1u : (djA + 7u) >> 3) : 0u;
@@ -473,8 +489,8 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                             const uint32_t tA = (uint32_t)__builtin_amdgcn_readlane((int)inclA, 63);
                             const uint32_t baseA = qt + inclA - partsA, baseB = qt + tA + inclB - partsB;
                             for (uint32_t pp = 0; pp < maxparts; ++pp) {
-                                if (pp < partsA) slots[baseA + pp] = make_uint2(jA | (min(8u, djA - 8u * pp) << 16) | (pp << 24), rjA + 8u * pp);
-                                if (pp < partsB) slots[baseB + pp] = make_uint2(jB | (min(8u, djB - 8u * pp) << 16) | (pp << 24), rjB + 8u * pp);
+                                if (pp < partsA) slots[baseA + pp] = make_uint2(jA | (min(8u, djA - 8u * pp) << 16) | (pp << kPartShift), rjA + 8u * pp);
+                                if (pp < partsB) slots[baseB + pp] = make_uint2(jB | (min(8u, djB - 8u * pp) << 16) | (pp << kPartShift), rjB + 8u * pp);
                             }
                             qt += tA + (uint32_t)__builtin_amdgcn_readlane((int)inclB, 63);
                         }
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 const uint32_t K = min(qt - head, 8u);
                 uint2 ent = make_uint2(0u, 0u);
                 if (g8 < K) ent = slots[head + g8];
-                const bool act = s8 < ((ent.x >> 16) & 0xFFu);
+                const bool act = s8 < ((ent.x >> 16) & 0xFu);
                 const uint32_t e = act ? ent.y + s8 : 0u;
                 const double r = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
                 const uint32_t j = colAt(e);
@@ -515,14 +531,14 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                         const uint64_t bm = __ballot(big);
                         const uint32_t base = qt + (uint32_t)mbcnt(wm) + (uint32_t)mbcnt(bm);
                         if (win) slots[base] = make_uint2(j | (min(8u, dj) << 16), rj);
-                        if (big) slots[base + 1u] = make_uint2(j | ((dj - 8u) << 16) | (1u << 24), rj + 8u);
+                        if (big) slots[base + 1u] = make_uint2(j | ((dj - 8u) << 16) | (1u << kPartShift), rj + 8u);
                         qt += (uint32_t)__popcll((unsigned long long)wm) + (uint32_t)__popcll((unsigned long long)bm);
                     } else {
                         const uint32_t parts = win ? (dj <= 8u ? 1u : (dj + 7u) >> 3) : 0u;
                         const uint32_t incl = wave_scan_add_u32(parts);
                         const uint32_t base = qt + incl - parts;
                         for (uint32_t pp = 0; pp < maxparts; ++pp)
-                            if (pp < parts) slots[base + pp] = make_uint2(j | (min(8u, dj - 8u * pp) << 16) | (pp << 24), rj + 8u * pp);
+                            if (pp < parts) slots[base + pp] = make_uint2(j | (min(8u, dj - 8u * pp) << 16) | (pp << kPartShift), rj + 8u * pp);
                         qt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     }
                     qn += (uint32_t)__popcll((unsigned long long)wm);
@@ -581,7 +597,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     double qe[4]; uint32_t jj[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const bool act = s8 < ((ent[u].x >> 16) & 0xFFu);
+                        const bool act = s8 < ((ent[u].x >> 16) & 0xFu);
                         const uint32_t e = act ? ent[u].y + s8 : 0u;
                         const double qx = qv[e];
                         qe[u] = act ? qx : -1.0;
@@ -607,7 +623,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                 int mn = 0x7FFFFFFF;
                 for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) {
                     const uint32_t ex = slots[h].x;
-                    if ((ex >> 24) != 0u) continue;
+                    if ((ex >> kPartShift) != 0u) continue;
                     const uint32_t i = ex & 0xFFFFu;
 #pragma unroll
                     for (int k = 0; k < kSumStride; ++k) mc[k] += recAt(i, k);
@@ -665,6 +681,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             MC_PHASE(7);
             // ---- FastMetropolisHastings::iterate (MCMC.h:218-227) ----
             if (kase == 0) logprop = det_log(prop);
+            last_targetL = targetL; last_prop = prop;
             const double aL = targetL + logprop;
             const double acc = det_exp(aL);
             const double r = r_mh;  // always drawn
@@ -753,6 +770,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
         a.n_case[(size_t)chain * 3 + 2] = n_case2;
         a.status[chain] = status;
         a.top_count[chain] = top_count; a.top_hash[chain] = top_hash; a.overflow[chain] = overflow;
+        a.last_targetL[chain] = last_targetL; a.last_prop[chain] = last_prop;
     }
 }
 
@@ -823,6 +841,42 @@ __global__ __launch_bounds__(64) void chain_init_kernel(ChainArgs a)
         a.n_case[(size_t)chain * 3 + 2] = 0ull;
         a.status[chain] = inf_flag ? -5 : (n > 0 ? 0 : -7);
         a.top_count[chain] = 0ull; a.top_hash[chain] = 0ull; a.overflow[chain] = 0ull;
+        a.last_targetL[chain] = 0.0; a.last_prop[chain] = 1.0;
+    }
+}
+
+// Statistics grows: every (hash, count) entry of a chain's old visit table goes to its new, larger one (same
+// probing as flush_stats).  One wavefront per chain; the new table was zeroed on the stream before.
+__global__ __launch_bounds__(64) void visit_rehash_kernel(const unsigned long long* oh, const unsigned long long* oc, int ocap,
+                                                          unsigned long long* nh, unsigned long long* nc, int ncap)
+{
+    const int chain = (int)blockIdx.x;
+    const int lane = lane_id();
+    oh += (size_t)chain * ocap; oc += (size_t)chain * ocap;
+    nh += (size_t)chain * ncap; nc += (size_t)chain * ncap;
+    for (int b = 0; b < ocap; b += kWave) {
+        const int i = b + lane;
+        const uint64_t c = i < ocap ? oc[i] : 0ull, h = i < ocap ? oh[i] : 0ull;
+        uint64_t live = __ballot(c != 0ull);
+        while (live) {
+            const int src = __ffsll((unsigned long long)live) - 1;
+            live &= live - 1;
+            const uint64_t hs = (uint64_t)__shfl((unsigned long long)h, src, kWave);
+            const uint64_t cs = (uint64_t)__shfl((unsigned long long)c, src, kWave);
+            const uint32_t h0 = (uint32_t)(hs % (uint64_t)ncap);
+            for (uint32_t p0 = 0; p0 < (uint32_t)ncap; p0 += kWave) {
+                const uint32_t p = p0 + (uint32_t)lane;
+                uint32_t idx = h0 + p;
+                if (idx >= (uint32_t)ncap) idx -= (uint32_t)ncap;
+                const bool in = p < (uint32_t)ncap;
+                const uint64_t m = __ballot(in && nc[idx] == 0ull);
+                if (m) {
+                    if (lane == __ffsll((unsigned long long)m) - 1) { nh[idx] = hs; nc[idx] = cs; }
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
     }
 }
 
@@ -970,6 +1024,13 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
         }
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_visit_rehash(const unsigned long long* oh, const unsigned long long* oc, int ocap, unsigned long long* nh,
+                               unsigned long long* nc, int ncap, int n_chains, hipStream_t st)
+{
+    hipLaunchKernelGGL(visit_rehash_kernel, dim3(n_chains), dim3(64), 0, st, oh, oc, ocap, nh, nc, ncap);
+    return hipGetLastError();
 }
 
 hipError_t launch_chain_energy(const ChainArgs& a, double* out, hipStream_t st)

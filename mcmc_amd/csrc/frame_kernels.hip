@@ -789,7 +789,10 @@ __global__ void local_fit_kernel(FitArgs a)
     const long long svb = m[8] - cy * m[6];
     const __int128 du = (__int128)n * suu - (__int128)su * su;
     const __int128 dvv = (__int128)n * svv - (__int128)sv * sv;
-    const bool ok = (n >= 10) && (du != 0) && (dvv != 0) && (sb != 0);
+    // isZeroDisparity (OverSegmentation.cpp:422-432) keeps a superpixel as soon as one entry is >= 0.5; entries
+    // are shorts widened through size_t (:148), so every non-zero value counts (a negative one becomes ~1.8e19):
+    // "some b != 0" <=> Sbb != 0 (a sum of squares), which no mix of signs can cancel
+    const bool ok = (n >= 10) && (du != 0) && (dvv != 0) && (m[9] != 0);
     a.valid[(size_t)frame * a.s_max + s] = ok ? 1 : 0;
     f[0] = (double)suu; f[1] = (double)suv; f[2] = (double)svv;
     f[3] = (double)su;  f[4] = (double)sv;  f[5] = (double)n;

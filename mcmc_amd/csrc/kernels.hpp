@@ -83,8 +83,8 @@ struct ChainArgs {
     int* status;
     unsigned long long* visit_hash; unsigned long long* visit_count; // [C][hcap]
     unsigned long long* overflow; unsigned long long* top_count; unsigned long long* top_hash;
+    double* last_targetL; double* last_prop;   // [C] ratios of the last step (Problem::propose's out-parameters)
     unsigned long long* marg;  // [F][s_max][lmax]
-    unsigned long long* dwell; // [C] post-burn-in steps spent in the current state, not yet booked
     uint8_t* trace; unsigned long long trace_stride; // optional
     unsigned long long* slots_g; // [C][queue slots] FIFO of the growth when the frame's tables do not fit LDS (else unused)
     unsigned long long* prof;  // optional: 12 per-phase cycle sums (diagnostic build of the 4-wave LDS variant)
@@ -107,6 +107,8 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st);
 hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out);
 size_t chain_run_global_slots(const ChainArgs& a, int s_used_max, int e2_used_max);
 hipError_t launch_chain_energy(const ChainArgs& a, double* out, hipStream_t st);
+hipError_t launch_visit_rehash(const unsigned long long* oh, const unsigned long long* oc, int ocap, unsigned long long* nh,
+                               unsigned long long* nc, int ncap, int n_chains, hipStream_t st);
 hipError_t launch_canonical_labels(const uint16_t* src, const uint8_t* valid, const int* S, int s_max,
                                    int n_chains, int chains_per_frame, uint16_t* dst, hipStream_t st);
 

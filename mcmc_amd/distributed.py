@@ -112,6 +112,35 @@ def reduce_marginals(marg: np.ndarray, shared_frames: bool = True) -> np.ndarray
     return out.cpu().numpy().view(np.uint64).reshape((world * m.shape[0],) + m.shape[1:])
 
 
+def gather_rows(row: np.ndarray) -> np.ndarray:
+    """All-gather of one small int64 row per rank -> array [world, len(row)] in rank order."""
+    import torch
+    r = np.ascontiguousarray(row, np.int64).reshape(-1)
+    dist = _dist()
+    if dist is None:
+        return r.reshape(1, -1).copy()
+    dev = _device()
+    world = dist.get_world_size()
+    out = torch.empty(world * r.size, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, torch.from_numpy(r).to(dev))
+    return out.cpu().numpy().reshape(world, r.size)
+
+
+def sum_max(to_sum: np.ndarray, to_max: np.ndarray) -> np.ndarray:
+    """All-reduce of two small int64 vectors, one by SUM and one by MAX; returns them concatenated."""
+    import torch
+    a = np.ascontiguousarray(to_sum, np.int64).reshape(-1)
+    b = np.ascontiguousarray(to_max, np.int64).reshape(-1)
+    dist = _dist()
+    if dist is None:
+        return np.concatenate([a, b])
+    dev = _device()
+    ta = torch.from_numpy(a.copy()).to(dev); tb = torch.from_numpy(b.copy()).to(dev)
+    dist.all_reduce(ta, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+    return np.concatenate([ta.cpu().numpy(), tb.cpu().numpy()])
+
+
 def merge_visits(visits: dict) -> dict:
     """Statistics::update across ranks for ONE shared frame: sum of visit counts per
     state hash (small python dicts; object gather, once per run)."""

@@ -20,7 +20,8 @@ NOLABEL = 0xFFFF
 K_MOMENTS, K_LOCAL_FIT, K_EDGE_PROB, K_CHAIN = 0, 1, 2, 3
 
 ERRORS = {-1: "MCMC_E_BADARG", -2: "MCMC_E_DEVICE", -3: "MCMC_E_STATE", -4: "MCMC_E_NAN_RATIO",
-          -5: "MCMC_E_INF_ENERGY", -6: "MCMC_E_TOO_LARGE", -7: "MCMC_E_NOSUPERPIXELS"}
+          -5: "MCMC_E_INF_ENERGY", -6: "MCMC_E_TOO_LARGE", -7: "MCMC_E_NOSUPERPIXELS", -8: "MCMC_E_RANGE",
+          -9: "MCMC_E_OVERFLOW"}
 
 
 class McmcError(RuntimeError):
@@ -88,6 +89,9 @@ def load():
         "mcmc_chains_get_labels": (i, [vp, i, i, vp]),
         "mcmc_chains_get_scalars": (i, [vp] + [vp] * 10),
         "mcmc_chains_get_visits": (i, [vp, vp, vp]),
+        "mcmc_chains_visit_capacity": (i, [vp]),
+        "mcmc_chains_reserve_visits": (i, [vp, u64]),
+        "mcmc_chains_get_last_ratios": (i, [vp, vp, vp]),
         "mcmc_frame_get_marginals": (i, [vp, i, vp]),
         "mcmc_chains_recompute_energy": (i, [vp, vp]),
         "mcmc_last_kernel_ms": (dbl, [vp, i]),
@@ -142,7 +146,7 @@ class Context:
     """One context per (thread, GPU): frames resident in HBM plus chains over them."""
 
     def __init__(self, width=640, height=480, device=0, disparity_variance=7.0, new_segment_prob=0.8,
-                 marginal_bins=64, visit_capacity=256):
+                 marginal_bins=64, visit_capacity=0):
         L = load()
         self.L = L
         self.p = Params(width, height, disparity_variance, new_segment_prob, marginal_bins, visit_capacity)
@@ -272,8 +276,25 @@ class Context:
         self._ck(self.L.mcmc_chains_get_scalars(self.h, *[v.ctypes.data_as(C.c_void_p) for v in d.values()]))
         return d
 
+    def visit_capacity(self):
+        return int(self.L.mcmc_chains_visit_capacity(self.h))
+
+    def reserve_visits(self, measured_steps):
+        self._ck(self.L.mcmc_chains_reserve_visits(self.h, int(measured_steps)))
+
+    def last_ratios(self):
+        """(targetRatio log, proposalRatio) of every chain's last step: Problem::propose's out-parameters."""
+        t = np.zeros(self.n_chains); p = np.zeros(self.n_chains)
+        self._ck(self.L.mcmc_chains_get_last_ratios(self.h, _ptr(t, np.float64), _ptr(p, np.float64)))
+        return t, p
+
+    def ordered_states(self, chain):
+        """Statistics::getOrderedStates (Statistics.h:50-70): (count, hash) of one chain, most visited first."""
+        v = self.visits()[chain]
+        return sorted(((c, h) for h, c in v.items()), key=lambda t: (-t[0], t[1]))
+
     def visits(self):
-        cap = self.p.visit_capacity
+        cap = self.visit_capacity()
         hh = np.zeros((self.n_chains, cap), np.uint64); cc = np.zeros((self.n_chains, cap), np.uint64)
         self._ck(self.L.mcmc_chains_get_visits(self.h, _ptr(hh, np.uint64), _ptr(cc, np.uint64)))
         return [{int(h): int(c) for h, c in zip(hh[k], cc[k]) if c} for k in range(self.n_chains)]

@@ -317,7 +317,10 @@ int orc_local_fit(const int64_t *mom, int W, int H, int S, double var,
         /* isLinear: all u equal or all v equal <=> N*Suu == Su^2 (integers) */
         __int128 du = (__int128)n * suu - (__int128)su * su;
         __int128 dv = (__int128)n * svv - (__int128)sv * sv;
-        int ok = (n >= 10) && (du != 0) && (dv != 0) && (sb != 0);
+        /* isZeroDisparity (OverSegmentation.cpp:422-432): dropped only if NO entry is >= 0.5.  Entries are shorts
+         * widened through size_t (OverSegmentation.cpp:148), so any non-zero value -- a negative one becomes
+         * ~1.8e19 -- keeps the superpixel: "some b != 0" <=> Sbb != 0 (sum of squares; signs cannot cancel). */
+        int ok = (n >= 10) && (du != 0) && (dv != 0) && (m[9] != 0);
         valid[s] = (uint8_t)ok;
         f[0] = (double)suu; f[1] = (double)suv; f[2] = (double)svv;
         f[3] = (double)su;  f[4] = (double)sv;  f[5] = (double)n;
@@ -507,6 +510,7 @@ typedef struct orc_chains {
     /* Statistics (Statistics.h:33-47): visit counts keyed by state hash */
     int hcap; orc_visit *visits; int *n_visits; uint64_t *overflow;
     uint64_t *top_count; uint64_t *top_hash; uint16_t *top_label;
+    double *last_targetL, *last_prop; /* Problem::propose's out-parameters of the last step (Problem.cpp:213-217) */
     /* marginals of first-appearance labels, summed over chains */
     int lmax; uint64_t *marg; /* S*lmax */
     /* scratch */
@@ -540,6 +544,7 @@ void orc_chains_free(orc_chains *c)
     free(c->n_accept); free(c->n_case); free(c->status); free(c->visits); free(c->n_visits);
     free(c->overflow); free(c->top_count); free(c->top_hash); free(c->top_label); free(c->marg);
     free(c->inC); free(c->mem); free(c->nbr); free(c->queue);
+    free(c->last_targetL); free(c->last_prop);
     free(c);
 }
 
@@ -577,6 +582,9 @@ orc_chains *orc_chains_create(int S, const double *fit, const uint8_t *valid,
     c->top_hash = (uint64_t *)calloc((size_t)n_chains, 8);
     c->top_label = (uint16_t *)malloc(sizeof(uint16_t) * NS);
     c->marg = (uint64_t *)calloc((size_t)S * (size_t)lmax, 8);
+    c->last_targetL = (double *)calloc((size_t)n_chains, 8);
+    c->last_prop = (double *)malloc((size_t)n_chains * 8);
+    for (int k = 0; k < n_chains; ++k) c->last_prop[k] = 1.0;
     c->inC = (uint8_t *)calloc((size_t)S, 1);
     c->mem = (uint8_t *)calloc((size_t)S, 1);
     c->nbr = (uint8_t *)calloc((size_t)S, 1);
@@ -782,6 +790,8 @@ static uint8_t chain_step(orc_chains *c, int k, uint64_t t)
         if (targetL != targetL || prop != prop) st = ORC_E_NAN_RATIO; /* Problem.cpp:216-217 */
     }
 
+    c->last_targetL[k] = targetL; c->last_prop[k] = prop;
+
     /* FastMetropolisHastings::iterate (MCMC.h:218-227) */
     double aL = targetL + orc_det_log(prop);
     double a = orc_det_exp(aL);
@@ -896,6 +906,11 @@ void orc_chains_get_visits(const orc_chains *c, uint64_t *out_hash, uint64_t *ou
             out_count[(size_t)k * c->hcap + i] = c->visits[(size_t)k * c->hcap + i].count;
         }
     }
+}
+void orc_chains_get_last_ratios(const orc_chains *c, double *targetL, double *prop)
+{
+    memcpy(targetL, c->last_targetL, (size_t)c->n_chains * 8);
+    memcpy(prop, c->last_prop, (size_t)c->n_chains * 8);
 }
 void orc_chains_get_marginals(const orc_chains *c, uint64_t *out)
 {

@@ -11,9 +11,9 @@
 
 template <class PROBLEM>
 struct FastMHShape {  // the control flow of FastMetropolisHastings::iterate (MCMC.h:207-238)
+    mutable long double targetRatio = 0, proposalRatio = 0;   // kept for the test: what propose handed over last
     typename PROBLEM::State* iterate(typename PROBLEM::State* state) const
     {
-        long double targetRatio, proposalRatio;
         typename PROBLEM::State* newState = PROBLEM::propose(*state, targetRatio, proposalRatio);
         long double aL = targetRatio + std::log(proposalRatio);
         long double a = std::exp(aL);
@@ -54,9 +54,12 @@ int main(int argc, char** argv)
         int accepted = 0;
         for (int i = 0; i < steps; ++i) {
             mcmc_amd::Problem::State* nx = mh.iterate(st);
-            if (nx != st && nx->accepted) accepted++;
+            // the chain is on the device: count what IT decided; whichever State the host-side draw keeps
+            // carries the chain's current hash
+            if (nx != st ? nx->accepted : false) accepted++;
             st = nx;
         }
+        printf("ratios %a %a\n", (double)mh.targetRatio, (double)mh.proposalRatio);
         printf("problem hash %lu accepted %d trace %lu\n", (unsigned long)st->hash_, accepted,
                (unsigned long)st->sampler->scalars().trace_hash[0]);
         // 2. batched path: the same chain (chain 0 of 4) in one launch

@@ -61,6 +61,7 @@ def lib():
     L.orc_chains_get_scalars.argtypes = [C.c_void_p] + [C.c_void_p] * 10
     L.orc_chains_get_visits.argtypes = [C.c_void_p, u64p, u64p, i32p]
     L.orc_chains_get_marginals.argtypes = [C.c_void_p, u64p]
+    L.orc_chains_get_last_ratios.argtypes = [C.c_void_p, f64p, f64p]
     L.orc_chains_recompute_energy.argtypes = [C.c_void_p, f64p]
     L.orc_mix64.restype = C.c_uint64; L.orc_mix64.argtypes = [C.c_uint64]
     L.orc_wave_sum.restype = C.c_double; L.orc_wave_sum.argtypes = [f64p]
@@ -131,7 +132,7 @@ class Chains:
     """Oracle sampler over one frame (mirrors mcmc_amd.host.Chains)."""
 
     def __init__(self, fit, valid, row_ptr, col, q, n_chains, seed, chain_offset=0,
-                 var=7.0, new_seg_prob=0.8, hcap=256, lmax=64):
+                 var=7.0, new_seg_prob=0.8, hcap=4096, lmax=64):
         self.S = fit.shape[0]
         self.n = n_chains
         self.hcap, self.lmax = hcap, lmax
@@ -174,6 +175,11 @@ class Chains:
         out = np.zeros((self.S, self.lmax), np.uint64)
         lib().orc_chains_get_marginals(self.h, out)
         return out
+
+    def last_ratios(self):
+        t = np.zeros(self.n); p = np.zeros(self.n)
+        lib().orc_chains_get_last_ratios(self.h, t, p)
+        return t, p
 
     def recompute_energy(self):
         out = np.zeros(self.n)

@@ -53,3 +53,7 @@ def test_adapter_matches_batched_path_and_oracle(tmp_path, scene_c2_small):
         assert int(lines[key][2]) == want_hash, key
         assert int(lines[key][6]) == want_trace, key
     assert int(lines["batched"][4]) == want_acc
+    # Problem::propose hands over the real ratios of the step (Problem.cpp:213-217), bit for bit the oracle's
+    t, p = orc.last_ratios()
+    assert float.fromhex(lines["ratios"][1]) == t[0] and float.fromhex(lines["ratios"][2]) == p[0]
+    assert np.isfinite(t[0]) and np.isfinite(p[0]) and p[0] > 0

@@ -41,6 +41,8 @@ def test_single_process_paths():
     m = np.arange(6, dtype=np.uint64).reshape(3, 2)
     assert np.array_equal(D.reduce_marginals(m), m)
     assert D.merge_visits({1: 2}) == {1: 2}
+    assert D.gather_rows(np.array([4, 5])).tolist() == [[4, 5]]
+    assert D.sum_max(np.array([3]), np.array([9])).tolist() == [3, 9]
 
 
 def _free_port():
@@ -72,7 +74,10 @@ def _worker(rank, world, port, q):
             for h, c in v.items():
                 vis[h] = vis.get(h, 0) + c
         vis = D.merge_visits(vis)
-        q.put((rank, be, cid, bl.tolist(), marg.tolist(), cat.shape, s["trace_hash"].tolist(), per, vis))
+        rows = D.gather_rows(np.array([off, rank * 10 + 1], np.int64))
+        sm = D.sum_max(np.array([cnt]), np.array([rank + 5]))
+        q.put((rank, be, cid, bl.tolist(), marg.tolist(), cat.shape, s["trace_hash"].tolist(), per, vis,
+               rows.tolist(), sm.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -117,3 +122,5 @@ def test_two_rank_gloo_matches_single_process():
         for h, c in v.items():
             tot[h] = tot.get(h, 0) + c
     assert res[0][8] == tot and res[1][8] == tot
+    for r in res:
+        assert r[9] == [[0, 1], [3, 11]] and r[10] == [6, 6]

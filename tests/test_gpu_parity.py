@@ -150,6 +150,16 @@ def _compare_chains(ctx, orc, frame=0, lo=0, hi=None):
             assert np.array_equal(ctx.labels(which, canon)[lo:hi, :S], orc.labels(which, canon)), (which, canon)
     assert np.array_equal(bits(ctx.recompute_energy()[lo:hi]), bits(orc.recompute_energy()))
     assert ctx.visits()[lo:hi] == orc.visits()
+    # Problem::propose's out-parameters of the last step (Problem.cpp:213-217)
+    gt, gp = ctx.last_ratios(); ot, op = orc.last_ratios()
+    assert np.array_equal(bits(gt[lo:hi]), bits(ot)) and np.array_equal(bits(gp[lo:hi]), bits(op))
+    # the running energy (sum of targetRatios over accepted moves) against a refit of every segment of the
+    # current labeling from its member list (Segment(superPixels), Graph.h:33-40), first chain of the block
+    lab = ctx.labels(0, False)[lo, :S]
+    tot = 0.0
+    for root in np.unique(lab[lab != 0xFFFF]):
+        tot += ctx.segment_probability(frame, np.flatnonzero(lab == root).astype(np.uint32))[0]
+    assert abs(tot - gs["energy"][lo]) <= 1e-9 * abs(tot), (tot, gs["energy"][lo])
 
 
 def test_chain_parity_small(scene_c2_small, gpu_ctx_factory):
@@ -361,6 +371,137 @@ def test_chain_parity_c5_share_full_size(gpu_ctx_factory):
         assert np.array_equal(lab[f * cpf:f * cpf + 2, :sc.n_superpixels], orc.labels()), f
 
 
+def test_statistics_at_baseline_step_count(gpu_ctx_factory):
+    # Statistics keeps every visited state (Statistics.h:30-47).  BASELINE step count (1000 burn-in + 10000
+    # measured) on the C2 scene (in fact ~120 distinct states per chain after burn-in, ~150 from the start).  The
+    # visit table is sized from the run (visit_capacity = 0, room for one new state per measured step, grown and
+    # re-hashed between launches): nothing can overflow, every count equals the oracle's (run with room for every
+    # state), and the most-visited labeling (can05_sampler.cpp:36) is the oracle's.
+    from mcmc_amd.scene import make_scene
+    sc = make_scene(seed=1)
+    S = sc.n_superpixels
+    ctx = gpu_ctx_factory()
+    ctx.frames_alloc(1, S, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(8, seed=1)
+    ctx.chains_run(1000, 10000)
+    orc = _oracle_chains(sc, 8, seed=1, hcap=16384)
+    orc.run(1000, 10000)
+    gs = ctx.scalars()
+    assert (gs["overflow"] == 0).all() and (orc.scalars()["overflow"] == 0).all()
+    gv = ctx.visits()
+    assert max(len(v) for v in gv) > 64
+    assert ctx.visit_capacity() >= 2 * 10000
+    _compare_chains(ctx, orc)
+    # Statistics::getOrderedStates: most visited first, and its head is the top state
+    od = ctx.ordered_states(3)
+    assert od[0] == (int(gs["top_count"][3]), int(gs["top_hash"][3]))
+    assert [c for c, _ in od] == sorted((c for c, _ in od), reverse=True) and sum(c for c, _ in od) == 10000
+    # continuing the run grows the table again and keeps what it held
+    ctx.chains_run(0, 15000)
+    orc2 = _oracle_chains(sc, 2, seed=1, hcap=65536)
+    orc2.run(1000, 25000)
+    assert ctx.visits()[:2] == orc2.visits()
+    assert np.array_equal(ctx.labels(2, True)[:2, :S], orc2.labels(2, True))
+
+
+def test_statistics_fixed_capacity_overflow_is_flagged(scene_c2_small, gpu_ctx_factory):
+    # a caller-fixed visit table that fills up: the visits that found no slot are counted exactly as the oracle
+    # counts them, and asking for the most-visited labeling says that it may be wrong
+    from mcmc_amd import host
+    sc = scene_c2_small
+    ctx = gpu_ctx_factory(width=sc.width, height=sc.height, visit_capacity=5)
+    ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(6, seed=9)
+    ctx.chains_run(50, 800)
+    orc = _oracle_chains(sc, 6, seed=9, hcap=5)
+    orc.run(50, 800)
+    gs, os_ = ctx.scalars(), orc.scalars()
+    assert gs["overflow"].sum() > 0 and np.array_equal(gs["overflow"], os_["overflow"])
+    assert ctx.visits() == orc.visits() and ctx.visit_capacity() == 5
+    assert np.array_equal(gs["top_count"], os_["top_count"]) and np.array_equal(gs["top_hash"], os_["top_hash"])
+    with pytest.raises(host.McmcError) as e:
+        ctx.labels(2, True)
+    assert e.value.code == -9
+    assert np.array_equal(ctx.labels(0, True)[:, :sc.n_superpixels], orc.labels(0, True))   # other read-backs unaffected
+
+
+def _hub_frame(W, H, S, seed, block=4):
+    """S superpixels of block x block pixels on one noisy plane, superpixel 0 adjacent to every other one (a hub
+    of degree S-1) plus a ring through the others: the graph is the caller's, not derived from the pixels."""
+    rng = np.random.default_rng(seed)
+    label = np.full((H, W), 0xFFFF, np.uint16)
+    per_row = W // block
+    assert S <= per_row * (H // block)
+    for s in range(S):
+        r, c = divmod(s, per_row)
+        label[r * block:(r + 1) * block, c * block:(c + 1) * block] = s
+    v, u = np.mgrid[0:H, 0:W]
+    disp = np.clip(np.rint(300 + 0.03 * u - 0.02 * v + rng.normal(0, 1.0, (H, W))), 1, 2047).astype(np.int16)
+    nb = [set() for _ in range(S)]
+    for s in range(1, S):
+        nb[0].add(s); nb[s].add(0)
+        t = s + 1 if s + 1 < S else 1
+        if t != s:
+            nb[s].add(t); nb[t].add(s)
+    rp = np.zeros(S + 1, np.uint32); col = []
+    for s in range(S):
+        col += sorted(nb[s]); rp[s + 1] = len(col)
+    return disp, label, rp, np.array(col, np.uint32)
+
+
+@pytest.mark.parametrize("S", [300, 2600])
+def test_chain_parity_hub_superpixel(gpu_ctx_factory, S):
+    # a superpixel with hundreds / thousands of neighbours takes many FIFO slots (one per 8 neighbours): the part
+    # index of a slot has 12 bits (degree up to 32760).  S = 300: tables in LDS, 38 parts; S = 2600: degree 2599,
+    # 325 parts (beyond the 8 bits round 1 had), tables behind L2.
+    from types import SimpleNamespace
+    W, H = 640, 480
+    disp, label, rp, col = _hub_frame(W, H, S, seed=S)
+    sc = SimpleNamespace(width=W, height=H, disp=disp, label=label, n_superpixels=S, row_ptr=rp, col=col)
+    ctx = gpu_ctx_factory(width=W, height=H)
+    ctx.frames_alloc(1, S, col.size)
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    ctx.chains_init(4, seed=12)
+    ctx.chains_set_trace(150)
+    ctx.chains_run(30, 120)
+    assert (ctx.last_variant() // 10 == 1) == (S == 300)
+    orc = _oracle_chains(sc, 4, seed=12)
+    st, tr = orc.run(30, 120, trace=True)
+    assert st == 0 and np.array_equal(ctx.trace(), tr)
+    _compare_chains(ctx, orc)
+
+
+def test_filter_nonzero_disparity_rule_and_extreme_strips(gpu_ctx_factory):
+    # A1 filter: isZeroDisparity (OverSegmentation.cpp:422-432) keeps a superpixel as soon as one disparity is
+    # non-zero; values of mixed sign that sum to zero must not drop it (sum of squares, not sum).
+    W, H = 64, 512
+    ctx = gpu_ctx_factory(width=W, height=H)
+    ctx.frames_alloc(2, 4, 8)
+    label = np.full((H, W), 0xFFFF, np.uint16); disp = np.zeros((H, W), np.int16)
+    label[0:4, 0:4] = 0; disp[0:4, 0:2] = 5; disp[0:4, 2:4] = -5          # sums to zero, not all zero: kept
+    label[8:12, 0:4] = 1                                                   # all zero: dropped
+    label[16:20, 0:4] = 2; disp[16:20, 0:4] = -3                           # all negative: kept (non-zero)
+    label[24:28, 0:4] = 3; disp[24, 0] = 1                                 # a single non-zero pixel: kept
+    ctx.frame_upload(0, disp, label, 4)
+    # K1's strip-local 32-bit sums at the extreme: one superpixel = a whole tall frame of +-32768 / 32767
+    rng = np.random.default_rng(5)
+    d1 = rng.choice(np.array([-32768, 32767], np.int16), (H, W)); d1[:, ::2] = -32768
+    l1 = np.zeros((H, W), np.uint16)
+    ctx.frame_upload(1, d1, l1, 1)
+    ctx.frames_moments()
+    assert ctx.local_fit(0)[1].tolist() == [1, 0, 1, 1]
+    _, ovalid, _ = O.local_fit(O.moments(disp, label, 4), W, H)
+    assert ovalid.tolist() == [1, 0, 1, 1]
+    assert np.array_equal(ctx.moments(0), O.moments(disp, label, 4))
+    assert np.array_equal(ctx.moments(1), O.moments(d1, l1, 1))
+    assert ctx.moments(1)[0, 9] == (d1.astype(np.int64) ** 2).sum()
+
+
 def test_error_paths(gpu_ctx_factory):
     from mcmc_amd import host
     ctx = gpu_ctx_factory(width=64, height=32)
@@ -375,8 +516,23 @@ def test_error_paths(gpu_ctx_factory):
     ctx.frame_upload(0, d, l, 3)
     with pytest.raises(host.McmcError):
         ctx.frame_set_graph(0, np.array([0, 1, 1, 2], np.uint32), np.array([7, 0], np.uint32))  # id out of range
+    with pytest.raises(host.McmcError):
+        ctx.frame_set_graph(0, np.array([0, 2, 2, 2], np.uint32), np.array([1, 1], np.uint32))  # duplicate neighbour
+    with pytest.raises(host.McmcError):
+        ctx.frame_set_graph(0, np.array([0, 2, 2, 2], np.uint32), np.array([2, 1], np.uint32))  # not ascending
+    with pytest.raises(host.McmcError):
+        ctx.frame_set_graph(0, np.array([0, 9, 2, 2], np.uint32), np.array([1, 2], np.uint32))  # row_ptr beyond e2
     ctx.frame_set_graph(0, np.array([0, 0, 0, 0], np.uint32), np.zeros(0, np.uint32))
     ctx.frames_moments(); ctx.frames_edge_probs()
     with pytest.raises(host.McmcError) as e:
         ctx.chains_init(2)                            # every superpixel fails the filter
     assert e.value.code == -7
+    # a superpixel with more neighbours than the growth FIFO can address (MCMC_MAX_DEGREE = 32760)
+    big = gpu_ctx_factory(width=64, height=32)
+    big.frames_alloc(1, 33000, 70000)
+    big.frame_upload(0, d, l, 33000)
+    rp = np.zeros(33001, np.uint32); rp[1:] = 32761          # superpixel 0 lists 32761 neighbours, the others none
+    col = np.arange(1, 32762, dtype=np.uint32)
+    with pytest.raises(host.McmcError) as e:
+        big.frame_set_graph(0, rp, col)
+    assert e.value.code == -6

@@ -199,3 +199,15 @@ def test_sampler_finds_planes():
             tot += 1
             agree += (lab[i] == lab[j]) == (sc.plane_of_sp[i] == sc.plane_of_sp[j])
     assert agree / tot > 0.8
+
+
+def test_filter_keeps_mixed_sign_disparities():
+    # isZeroDisparity (OverSegmentation.cpp:422-432) with the size_t widening of OverSegmentation.cpp:148: a
+    # superpixel is dropped only if EVERY disparity is zero; +5 / -5 summing to zero is kept
+    H, W = 32, 32
+    label = np.full((H, W), 0xFFFF, np.uint16); disp = np.zeros((H, W), np.int16)
+    label[0:4, 0:4] = 0; disp[0:4, 0:2] = 5; disp[0:4, 2:4] = -5
+    label[8:12, 0:4] = 1
+    label[16:20, 0:4] = 2; disp[16:20, 0:4] = -3
+    _, valid, _ = O.local_fit(O.moments(disp, label, 3), W, H)
+    assert valid.tolist() == [1, 0, 1]
