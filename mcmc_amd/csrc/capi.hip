@@ -68,7 +68,9 @@ struct mcmc_ctx {
     // frames
     int n_frames = 0, s_max = 0, e2_max = 0;
     size_t px = 0;
-    int16_t* d_disp = nullptr; uint16_t* d_label = nullptr;
+    size_t fstride = 0;      // pixels between two frames of a plane (>= px; padding spreads the frames over HBM channels)
+    int16_t* d_disp = nullptr; uint16_t* d_label = nullptr;   // d_label may sit `label_skew` bytes into its allocation
+    uint16_t* d_label_alloc = nullptr;
     int* d_S = nullptr; uint32_t* d_E2 = nullptr; int* d_fstatus = nullptr;
     unsigned long long* d_mom = nullptr; double* d_fit = nullptr; uint8_t* d_valid = nullptr;
     double* d_lerr = nullptr; uint32_t* d_rowp = nullptr; uint32_t* d_col = nullptr; double* d_q = nullptr;
@@ -83,6 +85,7 @@ struct mcmc_ctx {
     bool ev_valid[K_COUNT]{};
     int chain_variant = 0;
     // tuning overrides (0 / -1 = automatic)
+    int opt_stride_pad = -1, opt_label_skew = -1;   // tuning: frame stride padding (pixels) / label plane offset (bytes)
     int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k1_version = 0, opt_k3_dense = 0;
     unsigned long long* d_prof = nullptr;
 };
@@ -128,7 +131,7 @@ void free_chains(Chains& h)
 
 void free_frames(mcmc_ctx* c)
 {
-    dfree(c->d_disp); dfree(c->d_label); dfree(c->d_S); dfree(c->d_E2); dfree(c->d_fstatus);
+    dfree(c->d_disp); dfree(c->d_label_alloc); c->d_label = nullptr; dfree(c->d_S); dfree(c->d_E2); dfree(c->d_fstatus);
     dfree(c->d_mom); dfree(c->d_fit); dfree(c->d_valid); dfree(c->d_lerr); dfree(c->d_rowp);
     dfree(c->d_col); dfree(c->d_q); dfree(c->d_marg); dfree(c->d_mem); dfree(c->d_segout);
     c->n_frames = 0;
@@ -280,6 +283,8 @@ int mcmc_ctx_set_option(mcmc_ctx* c, const char* name, int value)
     else if (n == "k3_profile") c->opt_k3_prof = value;
     else if (n == "k3_dense") c->opt_k3_dense = value;
     else if (n == "k1_version") c->opt_k1_version = value;
+    else if (n == "stride_pad") c->opt_stride_pad = value;      // takes effect at the next mcmc_frames_alloc
+    else if (n == "label_skew") c->opt_label_skew = value;
     else return fail(c, MCMC_E_BADARG, "set_option: unknown option " + n);
     return MCMC_OK;
 }
@@ -310,8 +315,14 @@ int mcmc_frames_alloc(mcmc_ctx* c, int n_frames, int s_max, int e2_max)
     free_chains(c->ch);
     free_frames(c);
     const size_t F = (size_t)n_frames;
-    HIPCHK(c, dalloc(&c->d_disp, F * c->px));
-    HIPCHK(c, dalloc(&c->d_label, F * c->px));
+    {
+        const size_t pad = c->opt_stride_pad >= 0 ? (size_t)c->opt_stride_pad : 0;
+        const size_t skew = c->opt_label_skew >= 0 ? (size_t)c->opt_label_skew : 0;
+        c->fstride = ((c->px + pad + 7) / 8) * 8;             // frames stay 16-byte aligned
+        HIPCHK(c, dalloc(&c->d_disp, F * c->fstride));
+        HIPCHK(c, dalloc(&c->d_label_alloc, F * c->fstride + (skew + 1) / 2 + 8));
+        c->d_label = c->d_label_alloc + ((skew / 16) * 16) / 2;
+    }
     HIPCHK(c, dalloc(&c->d_S, F));
     HIPCHK(c, dalloc(&c->d_E2, F));
     HIPCHK(c, dalloc(&c->d_fstatus, F));
@@ -340,8 +351,8 @@ static int upload_common(mcmc_ctx* c, int frame, const void* disp, const void* l
 {
     if (!frame_ok(c, frame) || !disp || !label || S <= 0 || S > c->s_max) return fail(c, MCMC_E_BADARG, "frame_upload: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->d_disp + (size_t)frame * c->px, disp, c->px * 2, kind, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_label + (size_t)frame * c->px, label, c->px * 2, kind, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_disp + (size_t)frame * c->fstride, disp, c->px * 2, kind, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_label + (size_t)frame * c->fstride, label, c->px * 2, kind, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_S + frame, &S, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // &S is a stack temporary
     c->h_S[frame] = S;
@@ -399,7 +410,7 @@ int mcmc_frames_moments(mcmc_ctx* c, int first, int count)
     const int W = c->p.width, H = c->p.height;
     MomentArgs a{};
     a.disp = c->d_disp; a.label = c->d_label; a.S = c->d_S; a.mom = c->d_mom;
-    a.frame_stride = c->px; a.W = W; a.H = H; a.s_max = c->s_max; a.first_frame = first;
+    a.frame_stride = c->fstride; a.W = W; a.H = H; a.s_max = c->s_max; a.first_frame = first;
     const bool generic = (W % 8) != 0 || W / 8 > 1024;
     int threads = 256, bands = 1, mode = 2;
     size_t lds = 0;

@@ -82,8 +82,11 @@ MC_D int sdot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
 constexpr uint32_t kOnes = 0x00010001u;
-// (1,1) in the halves of lw that equal the label replicated in pat
-MC_D uint32_t match01(uint32_t lw, uint32_t pat) { return pk_sub_u16(kOnes, pk_min_u16(lw ^ pat, kOnes)); }
+// unsigned saturating packed subtract: max(a - b, 0) per 16-bit half
+MC_D uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// (1,1) in the halves of lw that equal the label replicated in pat: 1 - (lw ^ pat) saturates to 0 unless the
+// half is 0 (two instructions; the min / subtract form takes three)
+MC_D uint32_t match01(uint32_t lw, uint32_t pat) { return pk_sub_u16_sat(kOnes, lw ^ pat); }
 
 // Sums of one 8-pixel chunk (one row v, columns u0..u0+7), all fit 32 bits but sbb.
 struct ChunkSums {
@@ -415,16 +418,21 @@ constexpr int kRecDwords = 12;     // 48 B per record
 constexpr int kQueueCap = 128;     // queued chunk positions per wave
 constexpr uint32_t kFlushL = 0xFFFEFFFFu, kFlushR = 0xFFFDFFFFu;   // never equal to a 16-bit label; low half 0xFFFF >= S
 
+// Running sums of one accumulator since the START of the strip: they are never restarted.  When the label an
+// accumulator follows changes from X to Y at row t, the sums S(t) so far are logged once with both labels and the
+// table gets  T[X] += S(t),  T[Y] -= S(t)  (the conversion to frame moments is linear): X has then received
+// S(t) - S(t_X), the sums of exactly its rows, without a lane-dependent reset of twelve registers in the hot loop.
 struct Acc {
     uint32_t lab;
     int32_t n, k1, k2, rn, rrn, rk, b0, bk, rb;
-    uint32_t bb_lo, bb_hi;
+    uint32_t bb32;              // sum b^2 of the rows whose disparities all fit 11 bits: < 2^32 over a whole strip
+    uint32_t bb_lo, bb_hi;      // sum b^2 of the other rows (64 bit)
 };
 
 MC_D void acc_reset(Acc& s, uint32_t lab)
 {
     s.lab = lab; s.n = 0; s.k1 = 0; s.k2 = 0; s.rn = 0; s.rrn = 0; s.rk = 0; s.b0 = 0; s.bk = 0; s.rb = 0;
-    s.bb_lo = 0; s.bb_hi = 0;
+    s.bb32 = 0; s.bb_lo = 0; s.bb_hi = 0;
 }
 
 MC_D int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
@@ -444,9 +452,10 @@ MC_D int sdot2z(uint32_t a, uint32_t b)   // dot2 with a zero addend, no registe
 }
 
 // Add the pixels selected by m[] (pairs of 0/1) of one chunk at strip row r (r2 = r*r); returns their count.
-// keep = 0 restarts the sums first (the accumulator was just logged), keep = ~0 continues them: the restart
-// is folded into the adds so that no lane-dependent branch touches the twelve registers.
-MC_D int acc_add_chunk(Acc& s, uint32_t keep, const uint32_t m[4], const uint32_t bw[4], int r, int r2)
+// WIDE (wave-uniform): some disparity of the row needs more than 11 bits, so its squares go to the 64-bit sum;
+// otherwise four dot products accumulate them in 32 bits (1024 pixels x 2047^2 < 2^32).
+template <bool WIDE>
+MC_D int acc_add_chunk(Acc& s, const uint32_t m[4], const uint32_t bw[4], int r, int r2)
 {
     const uint32_t b0 = bw[0], b1 = bw[1], b2 = bw[2], b3 = bw[3];   // disparities of the selected pixels, 0 elsewhere
     // the eight 0/1 flags as bytes of two dwords: count, sum k and sum k^2 are three v_dot4 pairs
@@ -454,60 +463,86 @@ MC_D int acc_add_chunk(Acc& s, uint32_t keep, const uint32_t m[4], const uint32_
     const uint32_t p23 = __builtin_amdgcn_perm(m[3], m[2], 0x06040200u);
     const int cnt = udot4(p23, 0x01010101u, udot4z(p01, 0x01010101u));
     const int kr = udot4(p23, 0x07060504u, udot4z(p01, 0x03020100u));
-    s.k2 = udot4(p23, 0x31241910u, udot4(p01, 0x09040100u, (int)((uint32_t)s.k2 & keep)));
+    s.k2 = udot4(p23, 0x31241910u, udot4(p01, 0x09040100u, s.k2));
     int br = sdot2z(b0, kOnes);
     br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
-    int bk = (int)((uint32_t)s.bk & keep);
+    int bk = s.bk;
     bk = sdot2(b0, 0x00010000u, bk);
     bk = sdot2(b1, 0x00030002u, bk); bk = sdot2(b2, 0x00050004u, bk); bk = sdot2(b3, 0x00070006u, bk);
     s.bk = bk;
-    // two squares <= 2^31 fit 32 bits read as unsigned for every int16 value; four may not
-    const uint32_t q0 = (uint32_t)sdot2z(b0, b0), q1 = (uint32_t)sdot2z(b1, b1);
-    const uint32_t q2 = (uint32_t)sdot2z(b2, b2), q3 = (uint32_t)sdot2z(b3, b3);
-    const uint64_t bb = (((uint64_t)(s.bb_hi & keep) << 32) | (s.bb_lo & keep)) + (((uint64_t)q0 + q1) + ((uint64_t)q2 + q3));
-    s.bb_lo = (uint32_t)bb; s.bb_hi = (uint32_t)(bb >> 32);
-    s.n = (int)((uint32_t)s.n & keep) + cnt;
-    s.k1 = (int)((uint32_t)s.k1 & keep) + kr;
-    s.b0 = (int)((uint32_t)s.b0 & keep) + br;
-    s.rn = mad24(r, cnt, (int)((uint32_t)s.rn & keep));
-    s.rrn = mad24(r2, cnt, (int)((uint32_t)s.rrn & keep));
-    s.rk = mad24(r, kr, (int)((uint32_t)s.rk & keep));
-    s.rb = mad24(r, br, (int)((uint32_t)s.rb & keep));
+    if constexpr (WIDE) {
+        // two squares <= 2^31 fit 32 bits read as unsigned for every int16 value; four may not
+        const uint32_t q0 = (uint32_t)sdot2z(b0, b0), q1 = (uint32_t)sdot2z(b1, b1);
+        const uint32_t q2 = (uint32_t)sdot2z(b2, b2), q3 = (uint32_t)sdot2z(b3, b3);
+        const uint64_t bb = (((uint64_t)s.bb_hi << 32) | s.bb_lo) + (((uint64_t)q0 + q1) + ((uint64_t)q2 + q3));
+        s.bb_lo = (uint32_t)bb; s.bb_hi = (uint32_t)(bb >> 32);
+    } else {
+        int q = (int)s.bb32;
+        q = sdot2(b0, b0, q); q = sdot2(b1, b1, q); q = sdot2(b2, b2, q); q = sdot2(b3, b3, q);
+        s.bb32 = (uint32_t)q;
+    }
+    s.n += cnt;
+    s.k1 += kr;
+    s.b0 += br;
+    s.rn = mad24(r, cnt, s.rn);
+    s.rrn = mad24(r2, cnt, s.rrn);
+    s.rk = mad24(r, kr, s.rk);
+    s.rb = mad24(r, br, s.rb);
     return cnt;
 }
 
-// strip-local sums -> frame moments, added to the table row of the label.  All products are
-// 24-bit or 32x32->64 (u0 < 2^13, vb < 2^12, n <= 1024, strip of <= 128 rows).
+// strip-local sums -> frame moments, added to the table row of lab_add and subtracted from the row of lab_sub
+// (either may be >= S: skipped).  All products are 24-bit or 32x32->64 (u0 < 2^13, vb < 2^12, n <= 1024, strip of
+// <= 128 rows); the table is int64 modulo 2^64, so a subtraction that comes before its addition is harmless.
+MC_D void sums_apply2(uint32_t lab_add, uint32_t lab_sub, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn,
+                      int rrn, int rk, int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S)
+{
+    const bool add = lab_add < (uint32_t)S, sub = lab_sub < (uint32_t)S;
+    if (!add && !sub) return;
+    const int su = __mul24((int)u0, n) + k1, sv = __mul24((int)vb, n) + rn;
+    const int x = __mul24((int)u0, rn) + rk;
+    unsigned long long v[kMomStride];
+    v[0] = (unsigned long long)(long long)n;
+    v[1] = (unsigned long long)(long long)su;
+    v[2] = (unsigned long long)(long long)sv;
+    v[3] = (unsigned long long)((long long)(int)u0 * (long long)(su + k1) + (long long)k2);
+    v[4] = (unsigned long long)((long long)(int)vb * (long long)su + (long long)x);
+    v[5] = (unsigned long long)((long long)(int)vb * (long long)(sv + rn) + (long long)rrn);
+    v[6] = (unsigned long long)(long long)b0;
+    v[7] = (unsigned long long)((long long)(int)u0 * (long long)b0 + (long long)bk);
+    v[8] = (unsigned long long)((long long)(int)vb * (long long)b0 + (long long)rb);
+    v[9] = ((unsigned long long)bb_hi << 32) | bb_lo;
+    if (add) {
+        unsigned long long* t = tab + (size_t)lab_add * kMomStride;
+#pragma unroll
+        for (int k = 0; k < kMomStride; ++k) atomicAdd(t + k, v[k]);
+    }
+    if (sub) {
+        unsigned long long* t = tab + (size_t)lab_sub * kMomStride;
+#pragma unroll
+        for (int k = 0; k < kMomStride; ++k) atomicAdd(t + k, 0ull - v[k]);
+    }
+}
 MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn, int rrn, int rk,
                      int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S)
 {
-    if (lab >= (uint32_t)S) return;
-    unsigned long long* t = tab + (size_t)lab * kMomStride;
-    const int su = __mul24((int)u0, n) + k1, sv = __mul24((int)vb, n) + rn;
-    const int x = __mul24((int)u0, rn) + rk;
-    atomicAdd(t + 0, (unsigned long long)(long long)n);
-    atomicAdd(t + 1, (unsigned long long)(long long)su);
-    atomicAdd(t + 2, (unsigned long long)(long long)sv);
-    atomicAdd(t + 3, (unsigned long long)((long long)(int)u0 * (long long)(su + k1) + (long long)k2));
-    atomicAdd(t + 4, (unsigned long long)((long long)(int)vb * (long long)su + (long long)x));
-    atomicAdd(t + 5, (unsigned long long)((long long)(int)vb * (long long)(sv + rn) + (long long)rrn));
-    atomicAdd(t + 6, (unsigned long long)(long long)b0);
-    atomicAdd(t + 7, (unsigned long long)((long long)(int)u0 * (long long)b0 + (long long)bk));
-    atomicAdd(t + 8, (unsigned long long)((long long)(int)vb * (long long)b0 + (long long)rb));
-    atomicAdd(t + 9, ((unsigned long long)bb_hi << 32) | bb_lo);
+    sums_apply2(lab, 0xFFFFFFFFu, u0, vb, n, k1, k2, rn, rrn, rk, b0, bk, rb, bb_lo, bb_hi, tab, S);
 }
 
 MC_D uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-MC_D void rec_write(uint32_t* wlog, int idx, const Acc& s, uint32_t u0, uint32_t vb)
+// record: the label the sums are added to (s.lab), the label they are subtracted from (lab_new), the strip's
+// origin and the running sums
+MC_D void rec_write(uint32_t* wlog, int idx, const Acc& s, uint32_t lab_new, uint32_t u0, uint32_t vb)
 {
+    const uint64_t bb = (((uint64_t)s.bb_hi << 32) | s.bb_lo) + (uint64_t)s.bb32;
     // three 16-byte LDS stores (the record stride and the log base are multiples of 16 bytes)
     typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4), aligned(16)));
     __attribute__((address_space(3))) lds_u32x4* q =
         (__attribute__((address_space(3))) lds_u32x4*)wlog + idx * (kRecDwords / 4);
     q[0] = lds_u32x4{ s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 16), (uint32_t)s.rn };
     q[1] = lds_u32x4{ (uint32_t)s.rrn, (uint32_t)s.rk, (uint32_t)s.b0, (uint32_t)s.bk };
-    q[2] = lds_u32x4{ (uint32_t)s.rb, s.bb_lo, s.bb_hi, 0u };
+    q[2] = lds_u32x4{ (uint32_t)s.rb, (uint32_t)bb, (uint32_t)(bb >> 32), lab_new };
 }
 
 MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int lane)
@@ -516,19 +551,19 @@ MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int 
     for (int i = lane; i < cnt; i += nact) {
         const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog, 16)) + i * (kRecDwords / 4);
         const uint4 a = q[0], b = q[1], c = q[2];
-        sums_apply(a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0xFFFFu), (int)(a.z >> 16),
-                   (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S);
+        sums_apply2(a.x & 0xFFFFu, c.w, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0xFFFFu), (int)(a.z >> 16),
+                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S);
     }
 }
 
 // append the accumulator of every lane in mask m (pred = this lane's bit); at most one record per lane, so a
 // log of 64 always has room after a drain (wave-uniform control flow)
-MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc& s, uint32_t u0, uint32_t vb,
-                     unsigned long long* tab, int S, int lane)
+MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc& s, uint32_t lab_new, uint32_t u0,
+                     uint32_t vb, unsigned long long* tab, int S, int lane, int dbg = 0)
 {
     const int k = __popcll((unsigned long long)m);
-    if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, lane); cnt = 0; }
-    if (pred) rec_write(wlog, cnt + mbcnt(m), s, u0, vb);
+    if (__builtin_expect(cnt + k > kRecCap, 0)) { if (dbg != 4) rec_drain(wlog, cnt, tab, S, lane); cnt = 0; }
+    if (pred && dbg != 5) rec_write(wlog, cnt + mbcnt(m), s, lab_new, u0, vb);
     cnt += k;
 }
 
@@ -596,7 +631,10 @@ MC_D uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 
 // RAGGED: some strip of the launch has fewer than R rows (H not a multiple of bands * nsub); lanes past
 // their strip then keep their labels and are masked out.  The common full-strip case pays nothing for it.
-template <bool TABLE_LDS, bool RAGGED>
+// STREAM (measurement only, option "k1_debug" = 1): the same launch shape, loads and waits with the arithmetic
+// replaced by an OR of the words read -- the rate this access pattern reaches on its own (bench.py reports it
+// beside the kernel's rate as roofline.stream_only_GBps).  It writes no moments.
+template <bool TABLE_LDS, bool RAGGED, bool STREAM = false>
 __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
@@ -656,7 +694,14 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     load_row(2, dC, lC);
     load_row(3, dD, lD);
     int r2 = 0;
+    uint32_t sink = 0;
     auto row = [&](const int it, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
+        if constexpr (STREAM) {
+            wait_vm<6>(d4, l4);
+            sink |= (d4.x | d4.y) | (d4.z | d4.w) | (l4.x | l4.y) | (l4.z | l4.w);
+            load_row(it + 4, d4, l4);
+            return;
+        }
         if (__builtin_expect(qcnt > kQueueCap - 64, 0)) {
             queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
             qcnt = 0;
@@ -683,25 +728,33 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
             bL[j] = pk_mul_lo_u16(dw[j], mL[j]);
             bR[j] = pk_mul_lo_u16(dw[j], mR[j]);
         }
-        // this set's words are consumed: fetch row it+4 into it
+        // rows whose disparities all fit 11 bits (every Kinect frame) take the 32-bit sum of squares
+        const uint64_t wide = ballot64((((dw[0] | dw[1]) | (dw[2] | dw[3])) & 0xF800F800u) != 0u);
+        // this set's words are consumed: fetch row it+4 into it.  (No use of lw[] / dw[] may follow: the loads
+        // land asynchronously in these registers, and a later use would make the compiler copy them before then.)
         load_row(it + 4, d4, l4);
 
-        // the left accumulator follows the label of pixel 0
-        const uint64_t emL = ballot64(evL);   // an accumulator that is still empty logs zeros: harmless
-        if (emL) rec_append(wlog, cnt, emL, evL, L, u0, (uint32_t)rs, tab, S, lane);
-        const uint32_t keepL = opaque(evL ? 0u : 0xFFFFFFFFu);
+        // the left accumulator follows the label of pixel 0: when that changes, the running sums are logged
+        // with both labels (added to the old one, subtracted from the new one)
+        const uint64_t emL = ballot64(evL);
+        if (emL && a.debug != 2) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, lane, a.debug);
         L.lab = l0;
         // the right accumulator follows the label of pixel 7 while that differs from pixel 0
         const uint64_t emR = ballot64(evR);
-        if (emR) rec_append(wlog, cnt, emR, evR, Rr, u0, (uint32_t)rs, tab, S, lane);
-        const uint32_t keepR = opaque(evR ? 0u : 0xFFFFFFFFu);
+        if (emR && a.debug != 2) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, lane, a.debug);
         Rr.lab = evR ? l7 : Rr.lab;
-        const int cL = acc_add_chunk(L, keepL, mL, bL, it, r2);
-        const int cR = acc_add_chunk(Rr, keepR, mR, bR, it, r2);
+        int cL, cR;
+        if (__builtin_expect(wide != 0, 0)) {
+            cL = acc_add_chunk<true>(L, mL, bL, it, r2);
+            cR = acc_add_chunk<true>(Rr, mR, bR, it, r2);
+        } else {
+            cL = acc_add_chunk<false>(L, mL, bL, it, r2);
+            cR = acc_add_chunk<false>(Rr, mR, bR, it, r2);
+        }
         // pixels in neither: queue the chunk
         const bool rest = live && (cL + cR != 8);
         const uint64_t rm = ballot64(rest);
-        if (rm) {
+        if (rm && a.debug != 2 && a.debug != 3) {
             if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | ((uint32_t)g << 16);
             qcnt += __popcll((unsigned long long)rm);
         }
@@ -718,12 +771,17 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     }
     // the last reloads are never consumed, but their registers must not be reused while they are in flight
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(dA), "+v"(lA), "+v"(dB), "+v"(lB), "+v"(dC), "+v"(lC), "+v"(dD), "+v"(lD) :: "memory");
+    if constexpr (STREAM) {
+        if (sink == 0x12345678u) wq[lane] = sink;    // keeps the loads alive; practically never taken
+        return;
+    }
     // flush: queued chunks, both accumulators, the log
     if (qcnt) queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
     {
-        const bool wl = L.n != 0, wr = Rr.n != 0;
-        rec_append(wlog, cnt, ballot64(wl), wl, L, u0, (uint32_t)rs, tab, S, lane);
-        rec_append(wlog, cnt, ballot64(wr), wr, Rr, u0, (uint32_t)rs, tab, S, lane);
+        // the end of the strip closes both accumulators: their sums go to the label they follow, nothing is subtracted
+        const bool wl = L.lab < (uint32_t)S, wr = Rr.lab < (uint32_t)S;
+        rec_append(wlog, cnt, ballot64(wl), wl, L, kFlushL, u0, (uint32_t)rs, tab, S, lane);
+        rec_append(wlog, cnt, ballot64(wr), wr, Rr, kFlushR, u0, (uint32_t)rs, tab, S, lane);
     }
     rec_drain(wlog, cnt, tab, S, lane);
 
@@ -944,6 +1002,18 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
         // ragged: some strip has fewer rows than the others
         const int rpb = (a.H + a.bands - 1) / a.bands, nsub = threads / (a.W / 8);
         const bool ragged = (a.H % a.bands) != 0 || (rpb % nsub) != 0;
+        if (a.debug == 1) {
+            static DeviceOnce onceS;
+            bool* attrS = onceS.slot();
+            if (!attrS || !*attrS) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, true, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                if (e != hipSuccess) return e;
+                if (attrS) *attrS = true;
+            }
+            hipLaunchKernelGGL((sp_moments_lr_kernel<true, true, true>), grid, dim3(threads), lds_bytes, st, a);
+            return hipGetLastError();
+        }
         if (mode == 3) {
             if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<true, true>), grid, dim3(threads), lds_bytes, st, a);
             else hipLaunchKernelGGL((sp_moments_lr_kernel<true, false>), grid, dim3(threads), lds_bytes, st, a);
