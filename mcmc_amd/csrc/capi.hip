@@ -86,7 +86,8 @@ struct mcmc_ctx {
     int chain_variant = 0;
     // tuning overrides (0 / -1 = automatic)
     int opt_stride_pad = -1, opt_label_skew = -1;   // tuning: frame stride padding (pixels) / label plane offset (bytes)
-    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k1_version = 0, opt_k3_dense = 0;
+    int opt_k1_px = 0;                               // left/right kernel: 0 automatic, 8 or 16 pixels per lane
+    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k3_dense = 0;
     unsigned long long* d_prof = nullptr;
 };
 
@@ -282,7 +283,7 @@ int mcmc_ctx_set_option(mcmc_ctx* c, const char* name, int value)
     else if (n == "k1_debug") c->opt_k1_debug = value;
     else if (n == "k3_profile") c->opt_k3_prof = value;
     else if (n == "k3_dense") c->opt_k3_dense = value;
-    else if (n == "k1_version") c->opt_k1_version = value;
+    else if (n == "k1_px") c->opt_k1_px = value;
     else if (n == "stride_pad") c->opt_stride_pad = value;      // takes effect at the next mcmc_frames_alloc
     else if (n == "label_skew") c->opt_label_skew = value;
     else return fail(c, MCMC_E_BADARG, "set_option: unknown option " + n);
@@ -416,23 +417,15 @@ int mcmc_frames_moments(mcmc_ctx* c, int first, int count)
     size_t lds = 0;
     if (generic) {
         bands = std::min(H, std::max(std::max(1, 256 / count), 64));
-    } else if (c->opt_k1_version == 2) {
-        // first-generation kernel (two slots with complement), kept for A/B measurements
-        const int g = W / 8;
-        if (g <= 512) { int k = std::max(1, 480 / g); threads = g * k; }
-        threads = std::min(threads, 512);
-        if (c->opt_k1_threads > 0) threads = std::min(512, c->opt_k1_threads);
-        mode = 0;
-        lds = moments_lds_bytes(s_used, threads);
-        if (lds > 96 * 1024 || c->opt_k1_lds == 0) { mode = 1; lds = moments_lds_bytes(0, threads); }
-        bands = std::max(1, 256 / count);
-        bands = std::min(bands, std::max(1, H / 32));
-        if (c->opt_k1_bands > 0) bands = std::min(c->opt_k1_bands, H);
     } else {
-        // left/right kernel: a workgroup is nsub sub-bands x G column strips, every strip at most
-        // 128 rows (32-bit strip-local sums); about one workgroup per CU or more
-        const int G = W / 8;
-        const int nsub_max = std::max(1, (c->opt_k1_threads > 0 ? std::min(1024, c->opt_k1_threads) : 1024) / G);
+        // left/right kernel: a workgroup is nsub sub-bands x G column strips of 8 or 16 pixels; a strip has at
+        // most 128 rows x 8 pixels or 64 rows x 16 pixels (32-bit strip-local sums); about one workgroup per CU or more
+        // 8 pixels per lane unless option "k1_px" = 16 asks for the 16-pixel form (measured slower at 640x480: half
+        // the waves, and the per-row work it shares is not what bounds the kernel)
+        const int npx = (c->opt_k1_px == 16 && W % 16 == 0) ? 16 : 8;
+        const int G = W / npx, max_rows = npx == 16 ? 64 : 128;
+        const int tmax = npx == 16 ? 512 : 1024;     // the 16-pixel form needs more registers per lane
+        const int nsub_max = std::max(1, (c->opt_k1_threads > 0 ? std::min(tmax, c->opt_k1_threads) : tmax) / G);
         bands = std::max(1, (256 + count - 1) / count);
         bands = std::min(bands, std::max(1, H / 8));
         if (c->opt_k1_bands > 0) bands = std::min(c->opt_k1_bands, H);
@@ -440,18 +433,19 @@ int mcmc_frames_moments(mcmc_ctx* c, int first, int count)
         for (;;) {
             const int rpb = (H + bands - 1) / bands;
             nsub = std::min(nsub_max, std::max(1, rpb / 4));
-            if ((rpb + nsub - 1) / nsub <= 128) break;
+            if ((rpb + nsub - 1) / nsub <= max_rows) break;
             bands++;
         }
         threads = G * nsub;
         mode = 3;
+        a.lane_px = npx;
         lds = moments_lr_lds_bytes(s_used, threads);
         if (lds > 160 * 1024 - 64 || c->opt_k1_lds == 0) { mode = 4; lds = moments_lr_lds_bytes(0, threads); }
     }
     a.bands = bands;
     a.table_rows = s_used;
     a.debug = c->opt_k1_debug;
-    if (bands > 1 || (mode != 0 && mode != 3))
+    if (bands > 1 || mode != 3)
         HIPCHK(c, hipMemsetAsync(c->d_mom + (size_t)first * c->s_max * MCMC_MOMENT_STRIDE, 0,
                                  (size_t)count * c->s_max * MCMC_MOMENT_STRIDE * 8, c->stream));
     {

@@ -18,15 +18,9 @@ namespace mc {
 // K1: moment accumulation.
 //
 // HBM layout: disp int16[F][H][W], label uint16[F][H][W]; 4 bytes per pixel are
-// read exactly once with 16-byte loads (8 pixels per lane per plane).  Threads
-// of a workgroup sweep a band of rows; when 8*blockDim is a multiple of W every
-// lane stays on the same 8-pixel-wide column strip from row to row, where the
-// superpixel label changes only every ~25 rows.  Each lane therefore keeps two
-// register-resident accumulator slots keyed by label (two, because a strip that
-// straddles a vertical superpixel boundary alternates between two labels) and
-// only touches LDS when a third label evicts one.  LDS holds one int64[S][10]
-// table per workgroup (ds_add_u64); at the end the non-zero rows are added to
-// HBM with 64-bit integer atomics.  All sums are integers, so the result is
+// read exactly once with 16-byte loads (8 pixels per lane per plane).  The
+// measured kernel is sp_moments_lr_kernel below; Slot is the plain accumulator
+// of the generic fallback (any width).  All sums are integers, so the result is
 // bit-identical for any band count, block size or arrival order.
 // ---------------------------------------------------------------------------
 struct Slot {
@@ -74,8 +68,6 @@ MC_D void slot_add1(Slot& s, int u, int v, int b)
 
 // packed 16-bit helpers: two pixels per dword, exactly as they sit in HBM
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-MC_D uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-MC_D uint32_t pk_sub_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 MC_D uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 MC_D int sdot2(uint32_t a, uint32_t b, int c)
 {
@@ -87,309 +79,6 @@ MC_D uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub
 // (1,1) in the halves of lw that equal the label replicated in pat: 1 - (lw ^ pat) saturates to 0 unless the
 // half is 0 (two instructions; the min / subtract form takes three)
 MC_D uint32_t match01(uint32_t lw, uint32_t pat) { return pk_sub_u16_sat(kOnes, lw ^ pat); }
-
-// Sums of one 8-pixel chunk (one row v, columns u0..u0+7), all fit 32 bits but sbb.
-struct ChunkSums {
-    int32_t n, su, sv, suu, suv, svv, sb, sub, svb;
-    uint64_t sbb;
-};
-
-// the pixels selected by m01[] (pairs of 0/1); dw[] holds the 8 int16 disparities.  Branch-free.
-MC_D ChunkSums chunk_masked(const uint32_t m01[4], const uint32_t dw[4], int u0, int v)
-{
-    const uint32_t np = (m01[0] + m01[1]) + (m01[2] + m01[3]);
-    const int nc = (int)((np & 0xFFFFu) + (np >> 16));
-    int km = sdot2(m01[0], 0x00010000u, 0);          // sum k   over selected pixels, k = 0..7
-    km = sdot2(m01[1], 0x00030002u, km);
-    km = sdot2(m01[2], 0x00050004u, km);
-    km = sdot2(m01[3], 0x00070006u, km);
-    int k2 = sdot2(m01[0], 0x00010000u, 0);          // sum k^2
-    k2 = sdot2(m01[1], 0x00090004u, k2);
-    k2 = sdot2(m01[2], 0x00190010u, k2);
-    k2 = sdot2(m01[3], 0x00310024u, k2);
-    const uint32_t b0 = pk_mul_lo_u16(dw[0], m01[0]), b1 = pk_mul_lo_u16(dw[1], m01[1]);
-    const uint32_t b2 = pk_mul_lo_u16(dw[2], m01[2]), b3 = pk_mul_lo_u16(dw[3], m01[3]);
-    int s1 = sdot2(b0, kOnes, 0);
-    s1 = sdot2(b1, kOnes, s1); s1 = sdot2(b2, kOnes, s1); s1 = sdot2(b3, kOnes, s1);
-    int sk = sdot2(b0, 0x00010000u, 0);
-    sk = sdot2(b1, 0x00030002u, sk); sk = sdot2(b2, 0x00050004u, sk); sk = sdot2(b3, 0x00070006u, sk);
-    // b*b <= 2^30 each: a pair sum fits 32 bits read as unsigned, the total needs 64
-    const uint32_t q0 = (uint32_t)sdot2(b0, b0, 0), q1 = (uint32_t)sdot2(b1, b1, 0);
-    const uint32_t q2 = (uint32_t)sdot2(b2, b2, 0), q3 = (uint32_t)sdot2(b3, b3, 0);
-    ChunkSums r;
-    r.n = nc;
-    r.su = u0 * nc + km;
-    r.sv = v * nc;
-    r.suu = u0 * (r.su + km) + k2;
-    r.suv = v * r.su;
-    r.svv = v * v * nc;
-    r.sb = s1;
-    r.sub = u0 * s1 + sk;
-    r.svb = v * s1;
-    r.sbb = ((uint64_t)q0 + (uint64_t)q1) + ((uint64_t)q2 + (uint64_t)q3);
-    return r;
-}
-
-// all 8 pixels of the chunk
-MC_D ChunkSums chunk_total(const uint32_t dw[4], int u0, int v)
-{
-    int s1 = sdot2(dw[0], kOnes, 0);
-    s1 = sdot2(dw[1], kOnes, s1); s1 = sdot2(dw[2], kOnes, s1); s1 = sdot2(dw[3], kOnes, s1);
-    int sk = sdot2(dw[0], 0x00010000u, 0);
-    sk = sdot2(dw[1], 0x00030002u, sk); sk = sdot2(dw[2], 0x00050004u, sk); sk = sdot2(dw[3], 0x00070006u, sk);
-    const uint32_t q0 = (uint32_t)sdot2(dw[0], dw[0], 0), q1 = (uint32_t)sdot2(dw[1], dw[1], 0);
-    const uint32_t q2 = (uint32_t)sdot2(dw[2], dw[2], 0), q3 = (uint32_t)sdot2(dw[3], dw[3], 0);
-    ChunkSums r;
-    r.n = 8;
-    r.su = 8 * u0 + 28;
-    r.sv = 8 * v;
-    r.suu = 8 * u0 * u0 + 56 * u0 + 140;
-    r.suv = v * r.su;
-    r.svv = 8 * v * v;
-    r.sb = s1;
-    r.sub = u0 * s1 + sk;
-    r.svb = v * s1;
-    r.sbb = ((uint64_t)q0 + (uint64_t)q1) + ((uint64_t)q2 + (uint64_t)q3);
-    return r;
-}
-
-MC_D ChunkSums chunk_sub(const ChunkSums& a, const ChunkSums& b)
-{
-    ChunkSums r;
-    r.n = a.n - b.n; r.su = a.su - b.su; r.sv = a.sv - b.sv; r.suu = a.suu - b.suu; r.suv = a.suv - b.suv;
-    r.svv = a.svv - b.svv; r.sb = a.sb - b.sb; r.sub = a.sub - b.sub; r.svb = a.svb - b.svb; r.sbb = a.sbb - b.sbb;
-    return r;
-}
-
-MC_D void slot_add_chunk(Slot& s, const ChunkSums& c)
-{
-    s.n += c.n; s.su += c.su; s.sv += c.sv; s.sb += c.sb;
-    s.suu += (int64_t)c.suu; s.suv += (int64_t)c.suv; s.svv += (int64_t)c.svv;
-    s.sub += (int64_t)c.sub; s.svb += (int64_t)c.svb; s.sbb += (int64_t)c.sbb;
-}
-
-MC_D void slot_swap(Slot& a, Slot& b) { Slot t = a; a = b; b = t; }
-
-// label of the first pixel selected by r01[] (pairs of 0/1, not all zero)
-MC_D uint32_t first_label(const uint32_t r01[4], const uint32_t lw[4])
-{
-    uint32_t L = lw[3] >> 16;
-    L = (r01[3] & 0xFFFFu) ? (lw[3] & 0xFFFFu) : L;
-    L = (r01[2] >> 16) ? (lw[2] >> 16) : L;
-    L = (r01[2] & 0xFFFFu) ? (lw[2] & 0xFFFFu) : L;
-    L = (r01[1] >> 16) ? (lw[1] >> 16) : L;
-    L = (r01[1] & 0xFFFFu) ? (lw[1] & 0xFFFFu) : L;
-    L = (r01[0] >> 16) ? (lw[0] >> 16) : L;
-    L = (r01[0] & 0xFFFFu) ? (lw[0] & 0xFFFFu) : L;
-    return L;
-}
-
-// K1 main kernel.  Per lane two accumulator slots: A = the label matched most
-// recently, B = the other.  Per 8-pixel chunk: A gets its pixels by a masked
-// packed-16-bit sum, B gets (chunk total - A's part): exact as long as every
-// pixel of the chunk is in A or B.  A pixel in neither slot (a new superpixel
-// started) evicts B.  Evicted slots are not added to the LDS table one lane at
-// a time (an LDS 64-bit atomic costs the CU ~64 cycles per wave-instruction
-// however few lanes are active): each wave appends them to a private LDS log
-// with plain stores and drains the log 64 records at a time, every lane
-// applying one record with 10 ds_add_u64.  Labels >= S (dropped pixels) are
-// tracked like any other label and discarded when their record is applied.
-constexpr int kLogCap = 32;       // records per wave
-constexpr int kLogStride = 12;    // u64 per record: label + 10 sums + pad (96 B, 16-B aligned)
-
-MC_D void log_apply(const unsigned long long* rec, unsigned long long* tab, int S)
-{
-    const uint32_t lab = (uint32_t)rec[0];
-    if (lab >= (uint32_t)S) return;
-    unsigned long long* t = tab + (size_t)lab * kMomStride;
-#pragma unroll
-    for (int k = 0; k < kMomStride; ++k) atomicAdd(t + k, rec[1 + k]);
-}
-
-MC_D void log_drain(unsigned long long* wlog, int cnt, unsigned long long* tab, int S, int lane)
-{
-    // the last wave of a block may be partial: stride by the lanes that exist (they are 0..nact-1)
-    const int nact = __popcll((unsigned long long)__ballot(true));
-    for (int i = lane; i < cnt; i += nact) log_apply(wlog + (size_t)i * kLogStride, tab, S);
-}
-
-MC_D void log_write(unsigned long long* rec, const Slot& s)
-{
-    rec[0] = (unsigned long long)s.lab;
-    rec[1] = (unsigned long long)(long long)s.n;
-    rec[2] = (unsigned long long)(long long)s.su;
-    rec[3] = (unsigned long long)(long long)s.sv;
-    rec[4] = (unsigned long long)s.suu;
-    rec[5] = (unsigned long long)s.suv;
-    rec[6] = (unsigned long long)s.svv;
-    rec[7] = (unsigned long long)(long long)s.sb;
-    rec[8] = (unsigned long long)s.sub;
-    rec[9] = (unsigned long long)s.svb;
-    rec[10] = (unsigned long long)s.sbb;
-}
-
-// Append the slot of every lane with `pred` to the wave's log (wave-uniform control flow).
-MC_D void log_append(unsigned long long* wlog, int& cnt, bool pred, const Slot& s, unsigned long long* tab, int S, int lane)
-{
-    uint64_t m = __ballot(pred && s.n != 0);
-    while (m) {
-        // take as many of the requesting lanes (lowest first) as the log has room for
-        if (cnt == kLogCap) { log_drain(wlog, cnt, tab, S, lane); cnt = 0; }
-        const int room = kLogCap - cnt;
-        const int rank = mbcnt(m);
-        const bool mine = ((m >> lane) & 1ull) && rank < room;
-        if (mine) log_write(wlog + (size_t)(cnt + rank) * kLogStride, s);
-        const uint64_t taken = __ballot(mine);
-        cnt += __popcll((unsigned long long)taken);
-        m &= ~taken;
-    }
-}
-
-template <bool TABLE_LDS>
-__global__ __launch_bounds__(512) void sp_moments_kernel(MomentArgs a)
-{
-    extern __shared__ unsigned long long lds[];
-    const int frame = a.first_frame + (int)blockIdx.y;
-    const int band = (int)blockIdx.x;
-    const int S = a.S[frame];
-    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int W = a.W, H = a.H, G = W / 8;
-    unsigned long long* gmom = a.mom + (size_t)frame * a.s_max * kMomStride;
-    // TABLE_LDS: records are applied to an LDS table [table_rows][10] first; otherwise (table too
-    // large for LDS) straight to HBM with 64-bit integer atomics.
-    unsigned long long* tab = TABLE_LDS ? lds : gmom;
-    unsigned long long* wlog = lds + (TABLE_LDS ? (size_t)a.table_rows * kMomStride : 0) + (size_t)wave * kLogCap * kLogStride;
-
-    if (TABLE_LDS) {
-        for (int i = tid; i < S * kMomStride; i += T) tab[i] = 0ull;
-        __syncthreads();
-    }
-
-    const int rows_per_band = (H + a.bands - 1) / a.bands;
-    const int r0 = band * rows_per_band;
-    const int r1 = min(H, r0 + rows_per_band);
-    // chunk schedule of this thread: c0, c0 + stride, ... (count of them), chunk = 8 pixels
-    int c0, stride, count;
-    if (T % G == 0) {
-        // T/G sub-bands of consecutive rows: a lane stays on one 8-pixel column strip and walks
-        // DOWN it row by row, so its label changes only once per superpixel
-        const int nsub = T / G, p = tid / G, g = tid % G;
-        const int R = (r1 - r0 + nsub - 1) / nsub;
-        const int rs = r0 + p * R, re = min(r1, rs + R);
-        c0 = (rs - r0) * G + g; stride = G; count = max(0, re - rs);
-    } else {
-        const int nchunks = max(0, r1 - r0) * G;
-        c0 = tid; stride = T; count = tid < nchunks ? (nchunks - tid + T - 1) / T : 0;
-    }
-    const size_t base = (size_t)frame * a.frame_stride + (size_t)r0 * W;
-    const uint4* dp = reinterpret_cast<const uint4*>(a.disp + base);
-    const uint4* lp = reinterpret_cast<const uint4*>(a.label + base);
-    int v = r0 + (c0 * 8) / W;
-    int u0 = (c0 * 8) % W;
-    const int dv = (stride * 8) / W, du = (stride * 8) % W;
-
-    Slot A, B;
-    slot_reset(A, kNoLabel);   // an empty slot may collect dropped pixels; they are discarded on apply
-    slot_reset(B, kNoLabel);
-    int cnt = 0;               // records in this wave's log (wave-uniform)
-
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 d4 = zero4, l4 = zero4, d4n = zero4, l4n = zero4;
-    if (count > 0) { d4 = dp[c0]; l4 = lp[c0]; }
-    if (count > 1) { d4n = dp[c0 + stride]; l4n = lp[c0 + stride]; }
-    // the wave iterates while any of its lanes has chunks left, so that log appends stay wave-uniform
-    for (int it = 0; __ballot(it < count) != 0; ++it) {
-        // prefetch two chunks ahead
-        uint4 d4nn = zero4, l4nn = zero4;
-        if (it + 2 < count) { d4nn = dp[c0 + (it + 2) * stride]; l4nn = lp[c0 + (it + 2) * stride]; }
-        const bool live = it < count;
-        const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
-        const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
-        if (a.debug == 1) {  // tuning experiment: streaming only
-            A.sb += (int)(((lw[0] ^ lw[1]) ^ (lw[2] ^ lw[3])) ^ ((dw[0] ^ dw[1]) ^ (dw[2] ^ dw[3])));
-        } else {
-            // which pixels are A's, B's, or in neither slot
-            uint32_t mA[4], rest[4];
-            uint32_t anyA = 0, anyB = 0, anyR = 0;
-            {
-                const uint32_t patA = A.lab | (A.lab << 16), patB = B.lab | (B.lab << 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mA[j] = match01(lw[j], patA);
-                    const uint32_t mb = match01(lw[j], patB);
-                    rest[j] = kOnes ^ (mA[j] | mb);
-                    anyA |= mA[j]; anyB |= mb; anyR |= rest[j];
-                }
-            }
-            if (!live || a.debug == 2) anyR = 0;
-            // New labels take over the slots this chunk does not match (A first, then B); the old
-            // contents go to the wave's log.
-            const bool evictA = anyR != 0 && anyA == 0;
-            if (a.debug != 3) log_append(wlog, cnt, evictA, A, tab, S, lane);
-            if (evictA) {
-                const uint32_t L1 = first_label(rest, lw);
-                const uint32_t p1 = L1 | (L1 << 16);
-                slot_reset(A, L1);
-                anyR = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { mA[j] = match01(lw[j], p1); rest[j] &= ~mA[j]; anyR |= rest[j]; }
-            }
-            const bool evictB = anyR != 0 && anyB == 0;
-            if (a.debug != 3) log_append(wlog, cnt, evictB, B, tab, S, lane);
-            if (evictB) {
-                const uint32_t L2 = first_label(rest, lw);
-                const uint32_t p2 = L2 | (L2 << 16);
-                slot_reset(B, L2);
-                anyR = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { rest[j] &= ~match01(lw[j], p2); anyR |= rest[j]; }
-            }
-            const ChunkSums pa = chunk_masked(mA, dw, u0, v);
-            ChunkSums d = chunk_sub(chunk_total(dw, u0, v), pa);   // everything that is not A's
-            if (live) slot_add_chunk(A, pa);
-            // rare: further labels in the same 8 pixels: each becomes its own record
-            uint32_t left = anyR;
-            if (a.debug == 4 || a.debug == 3) left = 0;
-            while (__ballot(left != 0)) {
-                Slot C;
-                slot_reset(C, kNoLabel);
-                const bool has = left != 0;
-                if (has) {
-                    const uint32_t L3 = first_label(rest, lw);
-                    const uint32_t p3 = L3 | (L3 << 16);
-                    uint32_t m3[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { m3[j] = match01(lw[j], p3) & rest[j]; rest[j] &= ~m3[j]; }
-                    const ChunkSums pc = chunk_masked(m3, dw, u0, v);
-                    slot_reset(C, L3);
-                    slot_add_chunk(C, pc);
-                    d = chunk_sub(d, pc);
-                    left = (rest[0] | rest[1]) | (rest[2] | rest[3]);
-                }
-                log_append(wlog, cnt, has, C, tab, S, lane);
-            }
-            if (live) slot_add_chunk(B, d);
-        }
-        d4 = d4n; l4 = l4n; d4n = d4nn; l4n = l4nn;
-        u0 += du; v += dv;
-        if (u0 >= W) { u0 -= W; v += 1; }
-    }
-    log_append(wlog, cnt, true, A, tab, S, lane);
-    log_append(wlog, cnt, true, B, tab, S, lane);
-    log_drain(wlog, cnt, tab, S, lane);
-
-    if (!TABLE_LDS) return;
-    __syncthreads();
-    if (a.bands == 1) {
-        for (int i = tid; i < S * kMomStride; i += T) gmom[i] = tab[i];
-    } else {
-        for (int i = tid; i < S * kMomStride; i += T) {
-            unsigned long long x = tab[i];
-            if (x) atomicAdd(gmom + i, x);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // K1, left/right form (the measured path).
@@ -426,13 +115,13 @@ struct Acc {
     uint32_t lab;
     int32_t n, k1, k2, rn, rrn, rk, b0, bk, rb;
     uint32_t bb32;              // sum b^2 of the rows whose disparities all fit 11 bits: < 2^32 over a whole strip
-    uint32_t bb_lo, bb_hi;      // sum b^2 of the other rows (64 bit)
+                                // (the squares of the other rows are added to the table by the queue path)
 };
 
 MC_D void acc_reset(Acc& s, uint32_t lab)
 {
     s.lab = lab; s.n = 0; s.k1 = 0; s.k2 = 0; s.rn = 0; s.rrn = 0; s.rk = 0; s.b0 = 0; s.bk = 0; s.rb = 0;
-    s.bb32 = 0; s.bb_lo = 0; s.bb_hi = 0;
+    s.bb32 = 0;
 }
 
 MC_D int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
@@ -451,36 +140,40 @@ MC_D int sdot2z(uint32_t a, uint32_t b)   // dot2 with a zero addend, no registe
     return d;
 }
 
-// Add the pixels selected by m[] (pairs of 0/1) of one chunk at strip row r (r2 = r*r); returns their count.
-// WIDE (wave-uniform): some disparity of the row needs more than 11 bits, so its squares go to the 64-bit sum;
-// otherwise four dot products accumulate them in 32 bits (1024 pixels x 2047^2 < 2^32).
-template <bool WIDE>
-MC_D int acc_add_chunk(Acc& s, const uint32_t m[4], const uint32_t bw[4], int r, int r2)
+// One half (8 pixels, columns KB .. KB+7 of the lane's chunk) of a row: the pixels selected by m[] (pairs of 0/1),
+// bw[] = their disparities (0 elsewhere).  Count, sum k and sum b are chained through cnt / kr / br (the row's
+// totals feed the row-weighted sums once per row); sum k^2, sum k b and sum b^2 go straight to the accumulator.
+// Squares: four dot products accumulate them in 32 bits (1024 pixels x 2047^2 < 2^32); bsq[] is bw[] on rows whose
+// disparities all fit 11 bits and 0 on the others (wave-uniform), whose squares the queue path adds.
+template <int KB>
+MC_D void acc_add_half(Acc& s, const uint32_t m[4], const uint32_t bw[4], bool squares, int& cnt, int& kr, int& br)
 {
-    const uint32_t b0 = bw[0], b1 = bw[1], b2 = bw[2], b3 = bw[3];   // disparities of the selected pixels, 0 elsewhere
+    constexpr uint32_t K = (uint32_t)KB;
+    constexpr uint32_t w01 = (K) | ((K + 1) << 8) | ((K + 2) << 16) | ((K + 3) << 24);
+    constexpr uint32_t w23 = (K + 4) | ((K + 5) << 8) | ((K + 6) << 16) | ((K + 7) << 24);
+    constexpr uint32_t q01 = (K * K) | (((K + 1) * (K + 1)) << 8) | (((K + 2) * (K + 2)) << 16) | (((K + 3) * (K + 3)) << 24);
+    constexpr uint32_t q23 = ((K + 4) * (K + 4)) | (((K + 5) * (K + 5)) << 8) | (((K + 6) * (K + 6)) << 16) | (((K + 7) * (K + 7)) << 24);
+    const uint32_t b0 = bw[0], b1 = bw[1], b2 = bw[2], b3 = bw[3];
     // the eight 0/1 flags as bytes of two dwords: count, sum k and sum k^2 are three v_dot4 pairs
     const uint32_t p01 = __builtin_amdgcn_perm(m[1], m[0], 0x06040200u);
     const uint32_t p23 = __builtin_amdgcn_perm(m[3], m[2], 0x06040200u);
-    const int cnt = udot4(p23, 0x01010101u, udot4z(p01, 0x01010101u));
-    const int kr = udot4(p23, 0x07060504u, udot4z(p01, 0x03020100u));
-    s.k2 = udot4(p23, 0x31241910u, udot4(p01, 0x09040100u, s.k2));
-    int br = sdot2z(b0, kOnes);
-    br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
+    cnt = udot4(p23, 0x01010101u, udot4(p01, 0x01010101u, cnt));
+    kr = udot4(p23, w23, udot4(p01, w01, kr));
+    s.k2 = udot4(p23, q23, udot4(p01, q01, s.k2));
+    br = sdot2(b0, kOnes, br); br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
     int bk = s.bk;
-    bk = sdot2(b0, 0x00010000u, bk);
-    bk = sdot2(b1, 0x00030002u, bk); bk = sdot2(b2, 0x00050004u, bk); bk = sdot2(b3, 0x00070006u, bk);
+    bk = sdot2(b0, (K) | ((K + 1) << 16), bk); bk = sdot2(b1, (K + 2) | ((K + 3) << 16), bk);
+    bk = sdot2(b2, (K + 4) | ((K + 5) << 16), bk); bk = sdot2(b3, (K + 6) | ((K + 7) << 16), bk);
     s.bk = bk;
-    if constexpr (WIDE) {
-        // two squares <= 2^31 fit 32 bits read as unsigned for every int16 value; four may not
-        const uint32_t q0 = (uint32_t)sdot2z(b0, b0), q1 = (uint32_t)sdot2z(b1, b1);
-        const uint32_t q2 = (uint32_t)sdot2z(b2, b2), q3 = (uint32_t)sdot2z(b3, b3);
-        const uint64_t bb = (((uint64_t)s.bb_hi << 32) | s.bb_lo) + (((uint64_t)q0 + q1) + ((uint64_t)q2 + q3));
-        s.bb_lo = (uint32_t)bb; s.bb_hi = (uint32_t)(bb >> 32);
-    } else {
+    if (squares) {   // wave-uniform
         int q = (int)s.bb32;
         q = sdot2(b0, b0, q); q = sdot2(b1, b1, q); q = sdot2(b2, b2, q); q = sdot2(b3, b3, q);
         s.bb32 = (uint32_t)q;
     }
+}
+// the row's totals into the plain and the row-weighted sums
+MC_D void acc_add_row(Acc& s, int cnt, int kr, int br, int r, int r2)
+{
     s.n += cnt;
     s.k1 += kr;
     s.b0 += br;
@@ -488,7 +181,6 @@ MC_D int acc_add_chunk(Acc& s, const uint32_t m[4], const uint32_t bw[4], int r,
     s.rrn = mad24(r2, cnt, s.rrn);
     s.rk = mad24(r, kr, s.rk);
     s.rb = mad24(r, br, s.rb);
-    return cnt;
 }
 
 // strip-local sums -> frame moments, added to the table row of lab_add and subtracted from the row of lab_sub
@@ -535,14 +227,13 @@ MC_D uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // origin and the running sums
 MC_D void rec_write(uint32_t* wlog, int idx, const Acc& s, uint32_t lab_new, uint32_t u0, uint32_t vb)
 {
-    const uint64_t bb = (((uint64_t)s.bb_hi << 32) | s.bb_lo) + (uint64_t)s.bb32;
     // three 16-byte LDS stores (the record stride and the log base are multiples of 16 bytes)
     typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4), aligned(16)));
     __attribute__((address_space(3))) lds_u32x4* q =
         (__attribute__((address_space(3))) lds_u32x4*)wlog + idx * (kRecDwords / 4);
-    q[0] = lds_u32x4{ s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 16), (uint32_t)s.rn };
+    q[0] = lds_u32x4{ s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 14), (uint32_t)s.rn };   // k1 < 2^14, k2 < 2^18
     q[1] = lds_u32x4{ (uint32_t)s.rrn, (uint32_t)s.rk, (uint32_t)s.b0, (uint32_t)s.bk };
-    q[2] = lds_u32x4{ (uint32_t)s.rb, (uint32_t)bb, (uint32_t)(bb >> 32), lab_new };
+    q[2] = lds_u32x4{ (uint32_t)s.rb, s.bb32, 0u, lab_new };
 }
 
 MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int lane)
@@ -551,7 +242,7 @@ MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int 
     for (int i = lane; i < cnt; i += nact) {
         const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog, 16)) + i * (kRecDwords / 4);
         const uint4 a = q[0], b = q[1], c = q[2];
-        sums_apply2(a.x & 0xFFFFu, c.w, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0xFFFFu), (int)(a.z >> 16),
+        sums_apply2(a.x & 0xFFFFu, c.w, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0x3FFFu), (int)(a.z >> 14),
                     (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S);
     }
 }
@@ -559,41 +250,48 @@ MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int 
 // append the accumulator of every lane in mask m (pred = this lane's bit); at most one record per lane, so a
 // log of 64 always has room after a drain (wave-uniform control flow)
 MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc& s, uint32_t lab_new, uint32_t u0,
-                     uint32_t vb, unsigned long long* tab, int S, int lane, int dbg = 0)
+                     uint32_t vb, unsigned long long* tab, int S, int lane)
 {
     const int k = __popcll((unsigned long long)m);
-    if (__builtin_expect(cnt + k > kRecCap, 0)) { if (dbg != 4) rec_drain(wlog, cnt, tab, S, lane); cnt = 0; }
-    if (pred && dbg != 5) rec_write(wlog, cnt + mbcnt(m), s, lab_new, u0, vb);
+    if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, lane); cnt = 0; }
+    if (pred) rec_write(wlog, cnt + mbcnt(m), s, lab_new, u0, vb);
     cnt += k;
 }
 
-// work off the queued chunks: one chunk per lane; its pixels that match neither the left nor the right
-// label are added to the table directly (runs of one label merged; normally one run per chunk)
+// work off the queued chunks: one chunk (8 NQ pixels) per lane; its pixels that match neither the left nor the
+// right label are added to the table directly (runs of one label merged; normally one run per chunk)
+template <int NQ>
 MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const uint4* lpf, int G,
                         unsigned long long* tab, int S, int lane)
 {
+    constexpr int NP = 8 * NQ;
     const int nact = __popcll((unsigned long long)ballot64(true));
     for (int base = 0; base < qcnt; base += nact) {
         const bool act = base + lane < qcnt;
         const uint32_t ent = act ? wq[base + lane] : 0u;
-        const uint32_t row = ent & 0xFFFFu, g = ent >> 16;     // absolute row of the frame, strip index
-        uint4 l4 = make_uint4(0u, 0u, 0u, 0u), d4 = l4;
-        if (act) { l4 = lpf[(size_t)row * G + g]; d4 = dpf[(size_t)row * G + g]; }
-        const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
-        const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
-        const uint32_t l0 = lw[0] & 0xFFFFu, l7 = lw[3] >> 16;
+        const uint32_t row = ent & 0x7FFFu, g = ent >> 16;     // absolute row of the frame, strip index
+        const bool wide = (ent & 0x8000u) != 0u;               // a row with disparities beyond 11 bits: its squares too
+        uint32_t lw[4 * NQ], dw[4 * NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            uint4 l4 = make_uint4(0u, 0u, 0u, 0u), d4 = l4;
+            if (act) { l4 = lpf[((size_t)row * G + g) * NQ + q]; d4 = dpf[((size_t)row * G + g) * NQ + q]; }
+            lw[4 * q] = l4.x; lw[4 * q + 1] = l4.y; lw[4 * q + 2] = l4.z; lw[4 * q + 3] = l4.w;
+            dw[4 * q] = d4.x; dw[4 * q + 1] = d4.y; dw[4 * q + 2] = d4.z; dw[4 * q + 3] = d4.w;
+        }
+        const uint32_t l0 = lw[0] & 0xFFFFu, l7 = lw[4 * NQ - 1] >> 16;
         uint32_t clab = kNoLabel;
         int n = 0, k1 = 0, k2 = 0, b0 = 0, bk = 0;
         uint64_t bb = 0;
 #pragma unroll
-        for (int k = 1; k < 7; ++k) {
+        for (int k = 1; k < NP - 1; ++k) {
             const uint32_t lab = (k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu);
             const int b = (int)(short)((k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu));
             const bool isrest = act && lab != l0 && lab != l7;
             const bool emit = isrest && n != 0 && lab != clab;
             if (ballot64(emit)) {   // a second run of rest pixels in one chunk: rare
                 if (emit) {
-                    sums_apply(clab, g * 8u, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
+                    sums_apply(clab, g * (uint32_t)NP, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
                     n = 0; k1 = 0; k2 = 0; b0 = 0; bk = 0; bb = 0;
                 }
             }
@@ -602,48 +300,78 @@ MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const ui
                 bb += (uint64_t)(uint32_t)(b * b);
             }
         }
-        if (n != 0) sums_apply(clab, g * 8u, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
+        if (n != 0) sums_apply(clab, g * (uint32_t)NP, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
+        // The strip accumulators skipped the squares of this row (they keep them in 32 bits): add sum b^2 of the
+        // pixels that match the left or the right label here, one run of equal labels at a time (the pixels that
+        // match neither were added with their squares above).
+        if (ballot64(act && wide)) {
+            uint32_t rl = kNoLabel;
+            uint64_t rb2 = 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const uint32_t lab = (k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu);
+                const int b = (int)(short)((k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu));
+                const bool mine = act && wide && (lab == l0 || lab == l7);
+                const bool emit = mine && rb2 != 0 && lab != rl;
+                if (ballot64(emit)) {
+                    if (emit) {
+                        if (rl < (uint32_t)S) atomicAdd(tab + (size_t)rl * kMomStride + 9, (unsigned long long)rb2);
+                        rb2 = 0;
+                    }
+                }
+                if (mine) { rl = lab; rb2 += (uint64_t)((int64_t)b * (int64_t)b); }
+            }
+            if (rb2 != 0 && rl < (uint32_t)S) atomicAdd(tab + (size_t)rl * kMomStride + 9, (unsigned long long)rb2);
+        }
     }
 }
 
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
-// hand-issued 16-byte load and counted wait (the registers are tied to the wait so that no use can move above it)
-MC_D void gload16(u32x4v& dst, const void* p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-// the same with the frame's base address in an SGPR pair and a 32-bit byte offset per lane (one VALU add per
-// load instead of 64-bit address arithmetic)
+// hand-issued 16-byte loads and counted wait: the frame's base address in an SGPR pair, a 32-bit byte offset per
+// lane (one VALU add per row instead of 64-bit address arithmetic) and an immediate offset for the second quad
+template <int OFF>
 MC_D void gload16s(u32x4v& dst, uint32_t byte_off, const void* sbase)
 {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(byte_off), "s"(sbase), "n"(OFF) : "memory");
+}
+// the registers of a row set are tied to the wait so that no use can move above it
+template <int NQ> struct RowSet { u32x4v d[NQ], l[NQ]; };
+template <int N>
+MC_D void wait_vm(RowSet<1>& r)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.d[0]), "+v"(r.l[0]) : "n"(N) : "memory");
 }
 template <int N>
-MC_D void wait_vm(u32x4v& a, u32x4v& b)
+MC_D void wait_vm(RowSet<2>& r)
 {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.d[0]), "+v"(r.l[0]), "+v"(r.d[1]), "+v"(r.l[1]) : "n"(N) : "memory");
 }
 
 // value the optimiser cannot see through: keeps a 0 / ~0 mask a register that is ANDed (a select costs
 // 1.5x an AND on gfx950, and 5x in its VCC form)
 MC_D uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 
+// NQ: 16-byte quads per plane, row and lane -- a lane owns a strip 8 NQ pixels wide (NQ = 2 when the width is a
+// multiple of 16: the per-row work that does not depend on the pixel count -- label logic, row-weighted sums,
+// evictions and their LDS stores -- is then paid once per 16 pixels).
 // RAGGED: some strip of the launch has fewer than R rows (H not a multiple of bands * nsub); lanes past
 // their strip then keep their labels and are masked out.  The common full-strip case pays nothing for it.
 // STREAM (measurement only, option "k1_debug" = 1): the same launch shape, loads and waits with the arithmetic
 // replaced by an OR of the words read -- the rate this access pattern reaches on its own (bench.py reports it
 // beside the kernel's rate as roofline.stream_only_GBps).  It writes no moments.
-template <bool TABLE_LDS, bool RAGGED, bool STREAM = false>
-__global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
+template <int NQ, bool TABLE_LDS, bool RAGGED, bool STREAM = false, int NSET = 4>
+__global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(MomentArgs a)
 {
+    constexpr int NP = 8 * NQ;                 // pixels per lane and row; NSET = row sets in flight
+    constexpr int WAITN = 2 * NQ * (NSET - 1); // younger loads when a row is consumed
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
     const int frame = a.first_frame + (int)blockIdx.y;
     const int band = (int)blockIdx.x;
     const int S = a.S[frame];
     const int T = (int)blockDim.x, tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = uni(tid >> 6);
-    const int W = a.W, H = a.H, G = W / 8;
+    const int W = a.W, H = a.H, G = W / NP;
     unsigned long long* gmom = a.mom + (size_t)frame * a.s_max * kMomStride;
     unsigned long long* tab = TABLE_LDS ? lds : gmom;
     uint32_t* wbase = reinterpret_cast<uint32_t*>(lds + (TABLE_LDS ? (size_t)a.table_rows * kMomStride : 0)) +
@@ -661,10 +389,10 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     const int r1 = min(H, r0 + rows_per_band);
     // T = nsub * G (host): sub-band p, column strip g
     const int nsub = T / G, p = tid / G, g = tid % G;
-    const int R = (max(0, r1 - r0) + nsub - 1) / nsub;       // <= 128 (host): 32-bit strip-local sums
+    const int R = (max(0, r1 - r0) + nsub - 1) / nsub;       // <= 128 / NQ (host): 32-bit strip-local sums
     const int rs = r0 + p * R, re = min(r1, rs + R);
     const int count = max(0, re - rs);                        // == R for every lane unless RAGGED
-    const uint32_t u0 = (uint32_t)g * 8u;
+    const uint32_t u0 = (uint32_t)g * (uint32_t)NP;
     const size_t frame_base = ((size_t)frame * a.frame_stride) / 8;   // in uint4 units (W % 8 == 0)
     const uint4* dpf = reinterpret_cast<const uint4*>(a.disp) + frame_base;
     const uint4* lpf = reinterpret_cast<const uint4*>(a.label) + frame_base;
@@ -674,109 +402,128 @@ __global__ __launch_bounds__(1024) void sp_moments_lr_kernel(MomentArgs a)
     acc_reset(Rr, kFlushR);
     int cnt = 0, qcnt = 0;     // wave-uniform
 
-    // Four register sets hold the rows it .. it+3 of the strip.  The loads are issued by hand and
+    // NSET register sets hold the rows it .. it+3 of the strip.  The loads are issued by hand and
     // waited for with counted s_waitcnt (in-order return): a set is reloaded with row it+4 as soon as its
-    // words have been consumed, and a row only waits until all but the six younger loads have landed,
-    // so 6-8 KB per wave stay in flight under the arithmetic.  Every load is issued by every wave (row
-    // index clamped per lane; the last reloads re-read the strip's last row), otherwise the count of
-    // younger loads would not be the constant the wait relies on.
+    // words have been consumed, and a row only waits until all but the younger loads have landed,
+    // so 6-8 KB (NQ = 1) or 12-16 KB (NQ = 2) per wave stay in flight under the arithmetic.  Every load is issued
+    // by every wave (row index clamped per lane; the last reloads re-read the strip's last row), otherwise the
+    // count of younger loads would not be the constant the wait relies on.
     const int cl = max(count, 1);
-    const uint32_t safe0 = (uint32_t)(min(rs, H - 1) * G + g) * 16u;    // byte offset, < 2^25 per frame
-    const int G16 = G * 16;
-    auto load_row = [&](const int j, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
-        const uint32_t o = safe0 + (uint32_t)__mul24(RAGGED ? min(j, cl - 1) : min(j, R - 1), G16);
-        gload16s(d4, o, dpf);
-        gload16s(l4, o, lpf);
+    const int pitch = G * 16 * NQ;                                             // bytes per row of a plane
+    const uint32_t safe0 = (uint32_t)(min(rs, H - 1) * pitch + g * 16 * NQ);   // byte offset, < 2^25 per frame
+    auto load_row = [&](const int j, RowSet<NQ>& rr) __attribute__((always_inline)) {
+        const uint32_t o = safe0 + (uint32_t)__mul24(RAGGED ? min(j, cl - 1) : min(j, R - 1), pitch);
+        gload16s<0>(rr.d[0], o, dpf);
+        gload16s<0>(rr.l[0], o, lpf);
+        if constexpr (NQ == 2) {
+            gload16s<16>(rr.d[1], o, dpf);
+            gload16s<16>(rr.l[1], o, lpf);
+        }
     };
-    u32x4v dA = 0, lA = 0, dB = 0, lB = 0, dC = 0, lC = 0, dD = 0, lD = 0;
-    load_row(0, dA, lA);
-    load_row(1, dB, lB);
-    load_row(2, dC, lC);
-    load_row(3, dD, lD);
+    RowSet<NQ> sets[NSET];
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { sets[k].d[q] = 0; sets[k].l[q] = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) load_row(k, sets[k]);
     int r2 = 0;
     uint32_t sink = 0;
-    auto row = [&](const int it, u32x4v& d4, u32x4v& l4) __attribute__((always_inline)) {
+    auto row = [&](const int it, RowSet<NQ>& rr) __attribute__((always_inline)) {
         if constexpr (STREAM) {
-            wait_vm<6>(d4, l4);
-            sink |= (d4.x | d4.y) | (d4.z | d4.w) | (l4.x | l4.y) | (l4.z | l4.w);
-            load_row(it + 4, d4, l4);
+            wait_vm<WAITN>(rr);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                sink |= (rr.d[q].x | rr.d[q].y) | (rr.d[q].z | rr.d[q].w) | (rr.l[q].x | rr.l[q].y) | (rr.l[q].z | rr.l[q].w);
+            load_row(it + NSET, rr);
             return;
         }
         if (__builtin_expect(qcnt > kQueueCap - 64, 0)) {
-            queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
+            queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, lane);
             qcnt = 0;
         }
-        wait_vm<6>(d4, l4);
-        const uint32_t lw[4] = { l4.x, l4.y, l4.z, l4.w };
-        const uint32_t dw[4] = { d4.x, d4.y, d4.z, d4.w };
+        wait_vm<WAITN>(rr);
+        uint32_t lw[4 * NQ], dw[4 * NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            lw[4 * q] = rr.l[q].x; lw[4 * q + 1] = rr.l[q].y; lw[4 * q + 2] = rr.l[q].z; lw[4 * q + 3] = rr.l[q].w;
+            dw[4 * q] = rr.d[q].x; dw[4 * q + 1] = rr.d[q].y; dw[4 * q + 2] = rr.d[q].z; dw[4 * q + 3] = rr.d[q].w;
+        }
         const bool live = !RAGGED || it < count;
         // a lane that is past its strip keeps its labels
         const uint32_t l0 = live ? (lw[0] & 0xFFFFu) : L.lab;
-        const uint32_t l7 = live ? (lw[3] >> 16) : l0;
+        const uint32_t l7 = live ? (lw[4 * NQ - 1] >> 16) : l0;
         const bool evL = l0 != L.lab;
         const bool two = l7 != l0;
         const bool evR = two && l7 != Rr.lab;
         const uint32_t patL = l0 | (l0 << 16), patR = l7 | (l7 << 16);
         const uint32_t twoM = opaque((two && live) ? 0xFFFFFFFFu : 0u);
         const uint32_t liveM = RAGGED ? opaque(live ? 0xFFFFFFFFu : 0u) : 0xFFFFFFFFu;
-        uint32_t mL[4], mR[4], bL[4], bR[4];
+        uint32_t mL[4 * NQ], mR[4 * NQ], bL[4 * NQ], bR[4 * NQ];
+        uint32_t orb = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4 * NQ; ++j) {
             mL[j] = match01(lw[j], patL);
             if (RAGGED) mL[j] &= liveM;
             mR[j] = match01(lw[j], patR) & twoM;
             bL[j] = pk_mul_lo_u16(dw[j], mL[j]);
             bR[j] = pk_mul_lo_u16(dw[j], mR[j]);
+            orb |= dw[j];
         }
         // rows whose disparities all fit 11 bits (every Kinect frame) take the 32-bit sum of squares
-        const uint64_t wide = ballot64((((dw[0] | dw[1]) | (dw[2] | dw[3])) & 0xF800F800u) != 0u);
-        // this set's words are consumed: fetch row it+4 into it.  (No use of lw[] / dw[] may follow: the loads
+        const uint64_t wide = ballot64((orb & 0xF800F800u) != 0u);
+        // this set's words are consumed: fetch row it+NSET into it.  (No use of lw[] / dw[] may follow: the loads
         // land asynchronously in these registers, and a later use would make the compiler copy them before then.)
-        load_row(it + 4, d4, l4);
+        load_row(it + NSET, rr);
 
         // the left accumulator follows the label of pixel 0: when that changes, the running sums are logged
         // with both labels (added to the old one, subtracted from the new one)
         const uint64_t emL = ballot64(evL);
-        if (emL && a.debug != 2) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, lane, a.debug);
+        if (emL) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, lane);
         L.lab = l0;
-        // the right accumulator follows the label of pixel 7 while that differs from pixel 0
+        // the right accumulator follows the label of the last pixel while that differs from pixel 0
         const uint64_t emR = ballot64(evR);
-        if (emR && a.debug != 2) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, lane, a.debug);
+        if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, lane);
         Rr.lab = evR ? l7 : Rr.lab;
-        int cL, cR;
-        if (__builtin_expect(wide != 0, 0)) {
-            cL = acc_add_chunk<true>(L, mL, bL, it, r2);
-            cR = acc_add_chunk<true>(Rr, mR, bR, it, r2);
-        } else {
-            cL = acc_add_chunk<false>(L, mL, bL, it, r2);
-            cR = acc_add_chunk<false>(Rr, mR, bR, it, r2);
+        int cL = 0, kL = 0, brL = 0, cR = 0, kR = 0, brR = 0;
+        const bool squares = wide == 0;
+        acc_add_half<0>(L, mL, bL, squares, cL, kL, brL);
+        acc_add_half<0>(Rr, mR, bR, squares, cR, kR, brR);
+        if constexpr (NQ == 2) {
+            acc_add_half<8>(L, mL + 4, bL + 4, squares, cL, kL, brL);
+            acc_add_half<8>(Rr, mR + 4, bR + 4, squares, cR, kR, brR);
         }
-        // pixels in neither: queue the chunk
-        const bool rest = live && (cL + cR != 8);
+        acc_add_row(L, cL, kL, brL, it, r2);
+        acc_add_row(Rr, cR, kR, brR, it, r2);
+        // pixels in neither, or a row whose squares were left out: queue the chunk
+        const bool rest = live && (cL + cR != NP || !squares);
         const uint64_t rm = ballot64(rest);
-        if (rm && a.debug != 2 && a.debug != 3) {
-            if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | ((uint32_t)g << 16);
+        if (rm) {
+            if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | (squares ? 0u : 0x8000u) | ((uint32_t)g << 16);
             qcnt += __popcll((unsigned long long)rm);
         }
         r2 += 2 * it + 1;
     };
-    for (int it = 0; it < R; it += 4) {
-        row(it, dA, lA);
-        if (it + 1 >= R) break;
-        row(it + 1, dB, lB);
-        if (it + 2 >= R) break;
-        row(it + 2, dC, lC);
-        if (it + 3 >= R) break;
-        row(it + 3, dD, lD);
+    for (int it = 0; it < R; it += NSET) {
+        bool done = false;
+#pragma unroll
+        for (int k = 0; k < NSET; ++k) {
+            if (!done) {
+                row(it + k, sets[k]);
+                done = it + k + 1 >= R;
+            }
+        }
     }
     // the last reloads are never consumed, but their registers must not be reused while they are in flight
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dA), "+v"(lA), "+v"(dB), "+v"(lB), "+v"(dC), "+v"(lC), "+v"(dD), "+v"(lD) :: "memory");
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) wait_vm<0>(sets[k]);
     if constexpr (STREAM) {
         if (sink == 0x12345678u) wq[lane] = sink;    // keeps the loads alive; practically never taken
         return;
     }
     // flush: queued chunks, both accumulators, the log
-    if (qcnt) queue_process(wq, qcnt, dpf, lpf, G, tab, S, lane);
+    if (qcnt) queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, lane);
     {
         // the end of the strip closes both accumulators: their sums go to the label they follow, nothing is subtracted
         const bool wl = L.lab < (uint32_t)S, wr = Rr.lab < (uint32_t)S;
@@ -985,70 +732,57 @@ __global__ void selftest_philox_kernel(const uint32_t* ck, uint32_t* out)
 // ---------------------------------------------------------------------------
 hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, int mode, hipStream_t st)
 {
-    // mode 0: LDS table + log, 1: log only (HBM atomics per record), 2: generic (any width)
+    // mode 3: left/right kernel with the table in LDS, 4: the same with the table in HBM, 2: generic (any width)
     dim3 grid(a.bands, n_frames);
     if (mode == 3 || mode == 4) {
+        // a.lane_px: 8 or 16 pixels per lane and row (host: 16 only when W % 16 == 0)
+        const int npx = a.lane_px == 16 ? 16 : 8;
+        const void* fns[] = {
+            reinterpret_cast<const void*>(&sp_moments_lr_kernel<1, true, false>), reinterpret_cast<const void*>(&sp_moments_lr_kernel<1, true, true>),
+            reinterpret_cast<const void*>(&sp_moments_lr_kernel<2, true, false>), reinterpret_cast<const void*>(&sp_moments_lr_kernel<2, true, true>),
+            reinterpret_cast<const void*>(&sp_moments_lr_kernel<1, true, true, true>), reinterpret_cast<const void*>(&sp_moments_lr_kernel<2, true, true, true>) };
         static DeviceOnce once3;
         bool* attr3 = once3.slot();
         if (!attr3 || !*attr3) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-            if (e != hipSuccess) return e;
+            for (const void* f : fns) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                if (e != hipSuccess) return e;
+            }
             if (attr3) *attr3 = true;
         }
         // ragged: some strip has fewer rows than the others
-        const int rpb = (a.H + a.bands - 1) / a.bands, nsub = threads / (a.W / 8);
+        const int rpb = (a.H + a.bands - 1) / a.bands, nsub = threads / (a.W / npx);
         const bool ragged = (a.H % a.bands) != 0 || (rpb % nsub) != 0;
+        const dim3 blk(threads);
         if (a.debug == 1) {
-            static DeviceOnce onceS;
-            bool* attrS = onceS.slot();
-            if (!attrS || !*attrS) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_lr_kernel<true, true, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-                if (e != hipSuccess) return e;
-                if (attrS) *attrS = true;
+            if (npx == 16) hipLaunchKernelGGL((sp_moments_lr_kernel<2, true, true, true>), grid, blk, lds_bytes, st, a);
+            else hipLaunchKernelGGL((sp_moments_lr_kernel<1, true, true, true>), grid, blk, lds_bytes, st, a);
+        } else if (npx == 16) {
+            if (mode == 3) {
+                if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<2, true, true>), grid, blk, lds_bytes, st, a);
+                else hipLaunchKernelGGL((sp_moments_lr_kernel<2, true, false>), grid, blk, lds_bytes, st, a);
+            } else {
+                if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<2, false, true>), grid, blk, lds_bytes, st, a);
+                else hipLaunchKernelGGL((sp_moments_lr_kernel<2, false, false>), grid, blk, lds_bytes, st, a);
             }
-            hipLaunchKernelGGL((sp_moments_lr_kernel<true, true, true>), grid, dim3(threads), lds_bytes, st, a);
-            return hipGetLastError();
-        }
-        if (mode == 3) {
-            if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<true, true>), grid, dim3(threads), lds_bytes, st, a);
-            else hipLaunchKernelGGL((sp_moments_lr_kernel<true, false>), grid, dim3(threads), lds_bytes, st, a);
         } else {
-            if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<false, true>), grid, dim3(threads), lds_bytes, st, a);
-            else hipLaunchKernelGGL((sp_moments_lr_kernel<false, false>), grid, dim3(threads), lds_bytes, st, a);
+            if (mode == 3) {
+                if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<1, true, true>), grid, blk, lds_bytes, st, a);
+                else hipLaunchKernelGGL((sp_moments_lr_kernel<1, true, false>), grid, blk, lds_bytes, st, a);
+            } else {
+                if (ragged) hipLaunchKernelGGL((sp_moments_lr_kernel<1, false, true>), grid, blk, lds_bytes, st, a);
+                else hipLaunchKernelGGL((sp_moments_lr_kernel<1, false, false>), grid, blk, lds_bytes, st, a);
+            }
         }
         return hipGetLastError();
     }
-    if (mode == 2) {
-        hipLaunchKernelGGL(sp_moments_generic_kernel, grid, dim3(256), 0, st, a);
-    } else if (mode == 0) {
-        static DeviceOnce once0;
-        bool* attr_done = once0.slot();
-        if (!attr_done || !*attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_moments_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            if (attr_done) *attr_done = true;
-        }
-        hipLaunchKernelGGL(sp_moments_kernel<true>, grid, dim3(threads), lds_bytes, st, a);
-    } else {
-        hipLaunchKernelGGL(sp_moments_kernel<false>, grid, dim3(threads), lds_bytes, st, a);
-    }
+    hipLaunchKernelGGL(sp_moments_generic_kernel, grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
 size_t moments_lr_lds_bytes(int table_rows, int threads)
 {
     return (size_t)table_rows * kMomStride * 8 + (size_t)((threads + 63) / 64) * (kRecCap * kRecDwords + kQueueCap) * 4;
-}
-
-size_t moments_lds_bytes(int table_rows, int threads)
-{
-    return ((size_t)table_rows * kMomStride + (size_t)((threads + 63) / 64) * kLogCap * kLogStride) * 8;
 }
 
 hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st)

@@ -30,6 +30,7 @@ struct MomentArgs {
     int W, H, s_max, bands, first_frame;
     int table_rows;            // rows of the LDS table (>= every S in the launch)
     int debug;                 // tuning experiments only (0 = normal)
+    int lane_px;               // left/right kernel: pixels per lane and row, 8 or 16
 };
 
 struct FitArgs {
@@ -93,7 +94,6 @@ struct ChainArgs {
 };
 
 hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t lds_bytes, int mode, hipStream_t st);
-size_t moments_lds_bytes(int table_rows, int threads);
 size_t moments_lr_lds_bytes(int table_rows, int threads);
 hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st);
 hipError_t launch_edge_prob(const EdgeArgs& a, int n_frames, hipStream_t st);

@@ -97,6 +97,11 @@ def test_moments_full_size_bit_exact(gpu_ctx_factory, shape):
     m = sc.label < sc.n_superpixels
     assert ctx.moments(0)[:, 0].sum() == m.sum()
     assert ctx.moments(0)[:, 6].sum() == sc.disp[m].astype(np.int64).sum()
+    # the same integers from every launch shape: 16-pixel lanes (when the width allows), two bands, table in HBM
+    for opt, val in (("k1_px", 16), ("k1_bands", 2), ("k1_use_lds", 0)):
+        ctx.set_option(opt, val)
+        ctx.frames_moments()
+        assert np.array_equal(ctx.moments(0), want), (opt, val)
 
 
 def test_moments_edge_cases(gpu_ctx_factory):
@@ -500,6 +505,21 @@ def test_filter_nonzero_disparity_rule_and_extreme_strips(gpu_ctx_factory):
     assert np.array_equal(ctx.moments(0), O.moments(disp, label, 4))
     assert np.array_equal(ctx.moments(1), O.moments(d1, l1, 1))
     assert ctx.moments(1)[0, 9] == (d1.astype(np.int64) ** 2).sum()
+    # rows with disparities beyond 11 bits among ordinary rows, several labels per chunk: the squares of the wide
+    # rows take the queue path, the others the 32-bit strip sums
+    rng = np.random.default_rng(9)
+    d2 = rng.integers(0, 2047, (H, W)).astype(np.int16)
+    wide_rows = rng.random(H) < 0.2
+    d2[wide_rows] = rng.choice(np.array([-32768, 32767, 2048, -1, 5000], np.int16), (int(wide_rows.sum()), W))
+    l2 = (np.arange(W)[None, :] // 5 + (np.arange(H)[:, None] // 23) * 13).astype(np.uint16)
+    l2[rng.random((H, W)) < 0.02] = 0xFFFF
+    S2 = int(l2[l2 != 0xFFFF].max()) + 1
+    ctx.frames_alloc(1, S2, 8)
+    for px in (8, 16):
+        ctx.set_option("k1_px", px)
+        ctx.frame_upload(0, d2, l2, S2)
+        ctx.frames_moments()
+        assert np.array_equal(ctx.moments(0), O.moments(d2, l2, S2)), px
 
 
 def test_error_paths(gpu_ctx_factory):

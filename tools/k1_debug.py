@@ -7,15 +7,15 @@ g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "sm
 ci = int(os.environ.get("CASE", 0))
 disp, label, S, want = g[f"c{ci}_disp"], g[f"c{ci}_label"], int(g[f"c{ci}_S"]), g[f"c{ci}_moments"]
 H, W = disp.shape
-for ver in (0, 2):
+for ver in (8, 16):
     ctx = host.Context(width=W, height=H)
     ctx.frames_alloc(1, S, 8)
-    ctx.set_option("k1_version", ver)
+    ctx.set_option("k1_px", ver)
     ctx.frame_upload(0, disp, label, S)
     ctx.frames_moments()
     got = ctx.moments(0)
     bad = np.argwhere(got != want)
-    print("version", ver, "mismatching cells", len(bad), "superpixels", sorted(set(bad[:, 0].tolist())))
+    print("k1_px", ver, "mismatching cells", len(bad), "superpixels", sorted(set(bad[:, 0].tolist())))
     for s in sorted(set(bad[:, 0].tolist()))[:6]:
         ys, xs = np.nonzero(label == s)
         print("  sp", s, "rows", ys.min(), ys.max(), "cols", xs.min(), xs.max(), "diff", (got[s] - want[s]).tolist())

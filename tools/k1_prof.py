@@ -14,7 +14,7 @@ for f in range(F):
     sc = scs[f % 4]
     ctx.frame_upload(f, sc.disp, sc.label, sc.n_superpixels)
     alg += 640 * 480 * 4 + sc.n_superpixels * 80
-for k, v in (("k1_bands", "BANDS"), ("k1_threads", "THREADS"), ("k1_debug", "DEBUG"), ("k1_version", "VERSION")):
+for k, v in (("k1_bands", "BANDS"), ("k1_threads", "THREADS"), ("k1_debug", "DEBUG")):
     if v in os.environ:
         ctx.set_option(k, int(os.environ[v]))
 ctx.set_timing(True)

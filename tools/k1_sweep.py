@@ -19,9 +19,9 @@ ctx.set_timing(True)
 ref = None
 combos = [tuple(map(int, c.split(":"))) for c in sys.argv[1:]] or [(8, 320, 1, 0)]
 for combo in combos:
+    ctx.set_option("k1_px", combo[5] if len(combo) > 5 else 0)
     bands, threads, lds = combo[:3]
     dbg = combo[3] if len(combo) > 3 else 0
-    ctx.set_option("k1_version", combo[4] if len(combo) > 4 else 0)
     ctx.set_option("k1_debug", dbg)
     ctx.set_option("k1_bands", bands); ctx.set_option("k1_threads", threads); ctx.set_option("k1_use_lds", lds)
     for _ in range(3):
