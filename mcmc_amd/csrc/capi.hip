@@ -87,7 +87,7 @@ struct mcmc_ctx {
     // tuning overrides (0 / -1 = automatic)
     int opt_stride_pad = -1, opt_label_skew = -1;   // tuning: frame stride padding (pixels) / label plane offset (bytes)
     int opt_k1_px = 0;                               // left/right kernel: 0 automatic, 8 or 16 pixels per lane
-    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k3_dense = 0;
+    int opt_k1_bands = 0, opt_k1_threads = 0, opt_k1_lds = -1, opt_k1_debug = 0, opt_k3_prof = 0, opt_k3_dense = 0, opt_k3_spec = 0;
     unsigned long long* d_prof = nullptr;
 };
 
@@ -283,6 +283,7 @@ int mcmc_ctx_set_option(mcmc_ctx* c, const char* name, int value)
     else if (n == "k1_debug") c->opt_k1_debug = value;
     else if (n == "k3_profile") c->opt_k3_prof = value;
     else if (n == "k3_dense") c->opt_k3_dense = value;
+    else if (n == "k3_spec") c->opt_k3_spec = value;
     else if (n == "k1_px") c->opt_k1_px = value;
     else if (n == "stride_pad") c->opt_stride_pad = value;      // takes effect at the next mcmc_frames_alloc
     else if (n == "label_skew") c->opt_label_skew = value;
@@ -648,6 +649,7 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
         a.prof = c->d_prof;
     }
     a.dense_variant = c->opt_k3_dense;
+    a.spec_variant = c->opt_k3_spec;
     int s_used = 0, e_used = 0;
     const int frames_needed = (h.n + h.cpf - 1) / h.cpf;
     for (int f = 0; f < frames_needed; ++f) { s_used = std::max(s_used, c->h_S[f]); e_used = std::max(e_used, (int)c->h_E2[f]); }

@@ -149,9 +149,11 @@ struct SegFit {
 // LDS carve-up (all offsets multiples of 16 B).
 // ---------------------------------------------------------------------------
 struct LdsLayout {
-    size_t fit, q, col, rowp, vlist, sv, wave0, wave_bytes, total;
-    size_t w_label, w_slots, w_cl, w_nflag, w_rbits, w_rpre, w_rng;
+    size_t fit, q, col, rowp, vlist, sv, chain0, chain_bytes, wave0, wave_bytes, total;
+    size_t c_label, c_scal, c_ctl;                       // per chain: labels, shared scalars, control words (SPEC)
+    size_t w_slots, w_cl, w_nflag, w_rbits, w_rpre, w_rng;   // per wave
 };
+constexpr int kSpecScalars = 16;   // 64-bit words of a chain's scalars handed from wave to wave (speculative form)
 
 // queue slots: one per node of the component, plus one per further 8 neighbours of a node
 __host__ __device__ inline size_t queue_slots(int S, int E2) { return (size_t)S + (size_t)E2 / 8 + 8; }
@@ -160,7 +162,9 @@ __host__ __device__ inline size_t queue_slots(int S, int E2) { return (size_t)S 
 // leaves room for several chains per workgroup.
 // rec_lds: the per-superpixel records (88 B each) sit in LDS too; without them eight chains fit a workgroup
 // topo_lds: frames whose tables do not fit keep at least the CSR topology (row pointers, u16 columns) in LDS
-__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, bool rec_lds, bool topo_lds = false)
+// spec: two waves per chain (the speculative form): labels and scalars are per chain, the rest per wave
+__host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, bool rec_lds, bool topo_lds = false,
+                                                 bool spec = false)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsLayout L;
@@ -171,10 +175,15 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     L.rowp = o; if (tab_lds || topo_lds) o += A((size_t)(S + 1) * 4);
     L.vlist = o; o += A((size_t)S * 2);
     L.sv = o; o += 16;
-    L.wave0 = o;
     const size_t NW = (size_t)(S + 31) / 32;
+    size_t cb = 0;
+    L.c_label = cb; cb += A((size_t)S * 2);
+    L.c_scal = cb; if (spec) cb += (size_t)kSpecScalars * 8;
+    L.c_ctl = cb; if (spec) cb += 16;
+    L.chain0 = o; L.chain_bytes = cb;
+    o += cb * (size_t)wpb;
+    L.wave0 = o;
     size_t w = 0;
-    L.w_label = w; w += A((size_t)S * 2);
     L.w_slots = w; if (tab_lds) w += A(queue_slots(S, E2) * 8);
     L.w_cl = w; w += A((size_t)S * 4);
     L.w_nflag = w; w += A((size_t)S);
@@ -182,7 +191,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     L.w_rpre = w; w += A(NW * 4);
     L.w_rng = w; w += 4 * 64 * 8;
     L.wave_bytes = w;
-    L.total = o + w * (size_t)wpb;
+    L.total = o + w * (size_t)wpb * (spec ? 2u : 1u);
     return L;
 }
 
@@ -203,9 +212,21 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
 constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
 constexpr uint32_t kPartShift = 20u;       // FIFO slot word: node (16) | entries (4) | part (12)
 
-template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF, bool TOPO_LDS = false>
-__global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
+// SPEC: two wavefronts per chain.  A step's proposal is a pure function of (chain state, step index) -- the Philox
+// counter is (step, position) -- and at C2 about 94 % of the steps leave the state as it was, so a wave may
+// evaluate step t+1 against the state BEFORE step t has been decided and is right whenever t changes nothing.  Both
+// waves of a chain take step indices from a counter; a wave evaluates its step at once (read-only on the labels
+// and the segment cache, which belong to the chain; FIFO, claim words, flags and RNG batch are its own), then waits
+// for its turn -- steps commit strictly in order -- and, if an earlier step has changed the state meanwhile
+// (version word), evaluates again, now alone.  Committing (statistics, trace, relabel, cache rows, counters) is
+// the same code as in the one-wave form and runs in step order, so the chain is the same chain bit for bit; the
+// scalars it carries travel from wave to wave through LDS.  With one chain per SIMD the step is bound by the
+// latency of its dependent LDS round trips, and the second wave fills the issue slots the first leaves idle.
+// Waits are bounded: a wave that waits too long marks the chain failed (MCMC_E_DEVICE) instead of hanging.
+template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF, bool TOPO_LDS = false, bool SPEC = false>
+__global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
 {
+    constexpr int NT = WPB * 64 * (SPEC ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x;
     const int wave = uni(tid >> 6);            // scalar: addresses derived from it stay in SGPRs
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     const int S = a.S[frame];
     const int E2 = (int)a.E2[frame];
     const int NW = (S + 31) / 32;
-    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, REC_LDS, TOPO_LDS);
+    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, REC_LDS, TOPO_LDS, SPEC);
 
     const double* g_fit = a.fit + (size_t)frame * a.s_max * kFitStride;
     const double* g_q = a.q + (size_t)frame * a.e2_max;
@@ -231,15 +252,15 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     // ---- stage the frame tables (block-cooperative) ----
     if (TAB_LDS && REC_LDS) {
-        for (int i = tid; i < S * kRecStride; i += WPB * 64) {
+        for (int i = tid; i < S * kRecStride; i += NT) {
             const int sp = i / kRecStride, k = i - sp * kRecStride;
             l_fit[i] = g_fit[(size_t)sp * kFitStride + (k < 9 ? k : k + 3)];
         }
     }
-    if (TAB_LDS) for (int i = tid; i < E2; i += WPB * 64) l_q[i] = g_q[i];
+    if (TAB_LDS) for (int i = tid; i < E2; i += NT) l_q[i] = g_q[i];
     if (TAB_LDS || TOPO_LDS) {
-        for (int i = tid; i < E2; i += WPB * 64) l_col[i] = (uint16_t)g_col[i];
-        for (int i = tid; i <= S; i += WPB * 64) l_rowp[i] = g_rowp[i];
+        for (int i = tid; i < E2; i += NT) l_col[i] = (uint16_t)g_col[i];
+        for (int i = tid; i <= S; i += NT) l_rowp[i] = g_rowp[i];
     }
     // list of superpixels that passed the A1 filter, ascending (wave 0)
     int* s_Sv = reinterpret_cast<int*>(smem + L.sv);
@@ -259,11 +280,37 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
         if (lane == 0) *s_Sv = cnt;
         if (lane == 63) s_Sv[1] = (int)md;
     }
+    const int cw = SPEC ? (wave >> 1) : wave;      // chain within the workgroup
+    const int role = SPEC ? (wave & 1) : 0;        // which of the chain's two waves (SPEC)
+    const int chain = chain0 + cw;
+    unsigned char* cbase = smem + L.chain0 + (size_t)cw * L.chain_bytes;
+    uint16_t* label = reinterpret_cast<uint16_t*>(cbase + L.c_label);
+    unsigned long long* sscal = reinterpret_cast<unsigned long long*>(cbase + L.c_scal);   // SPEC only
+    volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(cbase + L.c_ctl);       // SPEC: next, committed, version, failed
+    uint16_t* g_label = a.label + (size_t)(chain < a.n_chains ? chain : 0) * a.s_max;
+    if (chain < a.n_chains && role == 0) {
+        // the chain's labels (and, in the speculative form, its scalars and control words) before anyone steps
+        for (int i = lane; i < S; i += kWave) label[i] = g_label[i];
+        if constexpr (SPEC) {
+            if (lane == 0) {
+                sscal[0] = (unsigned long long)__double_as_longlong(a.energy[chain]);
+                sscal[1] = (unsigned long long)__double_as_longlong(a.best_energy[chain]);
+                sscal[2] = a.state_hash[chain]; sscal[3] = a.trace_hash[chain]; sscal[4] = a.n_accept[chain];
+                sscal[5] = a.n_case[(size_t)chain * 3 + 0]; sscal[6] = a.n_case[(size_t)chain * 3 + 1];
+                sscal[7] = a.n_case[(size_t)chain * 3 + 2];
+                sscal[8] = (unsigned long long)(long long)a.status[chain];
+                sscal[9] = a.top_count[chain]; sscal[10] = a.top_hash[chain]; sscal[11] = a.overflow[chain];
+                sscal[12] = 0ull;   // dwell
+                sscal[13] = (unsigned long long)__double_as_longlong(a.last_targetL[chain]);
+                sscal[14] = (unsigned long long)__double_as_longlong(a.last_prop[chain]);
+                ctl[0] = 0u; ctl[1] = 0u; ctl[2] = 0u; ctl[3] = 0u;
+            }
+        }
+    }
     __syncthreads();
     const int Sv = *s_Sv;
     const uint32_t maxdeg = (uint32_t)s_Sv[1];
     const uint32_t maxparts = (maxdeg + 7u) >> 3;
-    const int chain = chain0 + wave;
     if (chain >= a.n_chains || Sv == 0) return;
 
     // ---- table accessors: LDS or HBM/L2 ----
@@ -281,11 +328,10 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
 
     // ---- wave-private state ----
     unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
-    uint16_t* label = reinterpret_cast<uint16_t*>(wbase + L.w_label);
     // FIFO of the growth: .x = node | entries << 16 (0..8, 4 bits) | part << 20 (12 bits: a node of up to
     // kMaxDegree neighbours), .y = first CSR entry of the part
     uint2* slots = TAB_LDS ? reinterpret_cast<uint2*>(wbase + L.w_slots)
-                           : reinterpret_cast<uint2*>(a.slots_g) + (size_t)chain * queue_slots(s_lds, e2_lds);
+                           : reinterpret_cast<uint2*>(a.slots_g) + ((size_t)chain * (SPEC ? 2 : 1) + role) * queue_slots(s_lds, e2_lds);
     // appends to the FIFO are read by other lanes of this wave in a later pass
     auto queue_fence = [&]() {
         if constexpr (TAB_LDS) wave_fence(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -297,10 +343,9 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     uint32_t* rbits = reinterpret_cast<uint32_t*>(wbase + L.w_rbits);
     uint32_t* rpre = reinterpret_cast<uint32_t*>(wbase + L.w_rpre);
 
-    uint16_t* g_label = a.label + (size_t)chain * a.s_max;
     // per-segment cache, row = the segment's name: 10 exact sums, sum of ssr, probabilityL, member count
     double* g_segC = a.segC + (size_t)chain * a.s_max * kSegCacheStride;
-    for (int i = lane; i < S; i += kWave) { label[i] = g_label[i]; cl[i] = kFree; }
+    for (int i = lane; i < S; i += kWave) cl[i] = kFree;
     for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
 
     double energy = a.energy[chain], best_energy = a.best_energy[chain];
@@ -393,306 +438,393 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
     unsigned long long pacc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long ptime = PROF ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long total = a.burn_in + a.iters;
-    for (unsigned long long ts = 0; ts < total; ++ts) {
-        const unsigned long long t = a.step0 + ts;
-        uint8_t tb = 0xFF;
-        if (status == 0) {
-            g.step_lo = (uint32_t)t; g.step_hi = (uint32_t)(t >> 32);
-            const u32x4 raw0 = rng_gen(g, 0, lane);
-            // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161); the step's other
-            // scalar draws are taken out of the batch now, before the growth moves on to later positions
-            const uint32_t start = vlist[(uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 0) % (uint32_t)Sv];
-            const double u1 = g.buf[2];
-            const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 3);
-            const double r_mh = g.buf[4];
-            const uint32_t orig = label[start];
-            // the old segment's cache row (sums, probabilityL, size): in flight during the growth
-            double Co[kSegCacheUsed];
-#pragma unroll
-            for (int k = 0; k < kSegCacheUsed; ++k) Co[k] = g_segC[(size_t)orig * kSegCacheStride + k];
-            MC_PHASE(0);
 
-            // ---- createComponent BFS (Segmentation.cpp:74-120), 8 queue slots x 8 neighbours per pass ----
-            // The reference pops one node at a time and tries its neighbours in order.  Here the FIFO is made of
-            // slots of at most 8 neighbours (a node with more takes consecutive slots), a pass takes the next 8
-            // slots, lane = 8 * slot + neighbour, and the trial of neighbour s of slot k owns the uniform at
-            // position 8 + 8 k + s (see Rng) whether or not it is needed.  A node reached through two open edges
-            // of one pass is taken by the lower lane, which is the edge the sequential loop reaches first, so the
-            // component and the FIFO order are exactly the sequential ones.
-            uint32_t qn = 1, qt, head = 0;
-            {
-                const uint32_t rs0 = rowp[start], d0 = rowp[start + 1] - rs0;
-                const uint32_t parts0 = d0 <= 8u ? 1u : (d0 + 7u) >> 3;
-                for (uint32_t pp = (uint32_t)lane; pp < parts0; pp += kWave)
-                    slots[pp] = make_uint2(start | (min(8u, d0 - 8u * pp) << 16) | (pp << kPartShift), rs0 + 8u * pp);
-                if (lane == 0) cl[start] = 0u;
-                qt = parts0;
-                queue_fence();
-            }
-            const uint32_t g8 = (uint32_t)lane >> 3, s8 = (uint32_t)lane & 7u;
-            while (head < qt) {
-                if (!TAB_LDS && qt - head > 8u) {
-                    // Tables and FIFO behind L2 (large frames: long round trips, wide frontiers): two passes' worth
-                    // of slots (head .. head+7 = A, head+8 .. head+15 = B) in one trip, so that their round trips
-                    // overlap.  The sequential order is kept by the claim priority (A's lanes 0..63 beat B's
-                    // 64..127: a node both reach goes to A, as it would if B ran after A) and by appending A's
-                    // winners before B's.  B reads the claim words before A's claims land; the lanes that lose the
-                    // claim this way are exactly those that would have found the node taken.  Trial positions are
-                    // per slot, so the draws do not move.  (With everything in LDS this measured 5 % slower.)
-                    const uint32_t K2 = min(qt - head, 16u);
-                    const uint2 entA = slots[head + g8];
-                    uint2 entB = make_uint2(0u, 0u);
-                    if (8u + g8 < K2) entB = slots[head + 8u + g8];
-                    const bool actA = s8 < ((entA.x >> 16) & 0xFu), actB = s8 < ((entB.x >> 16) & 0xFu);
-                    const uint32_t eA = actA ? entA.y + s8 : 0u, eB = actB ? entB.y + s8 : 0u;
-                    const double rA = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
-                    const double rB = rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), lane);
-                    const uint32_t jA = colAt(eA), jB = colAt(eB);
-                    const double qA = actA ? qv[eA] : -1.0, qB = actB ? qv[eB] : -1.0;
-                    const uint32_t cA = cl[jA], cB = cl[jB];
-                    const uint32_t lA = label[jA], lB = label[jB];
-                    const uint32_t rjA = rowp[jA], djA = rowp[jA + 1] - rjA;
-                    const uint32_t rjB = rowp[jB], djB = rowp[jB + 1] - rjB;
-                    const bool freshA = !(qA < 0.0) && cA == kFree, freshB = !(qB < 0.0) && cB == kFree;
-                    const bool joinA = freshA && lA == orig && (rA < qA);
-                    const bool joinB = freshB && lB == orig && (rB < qB);
-                    if (freshA && lA != orig) nflag[lA] = 1;
-                    if (freshB && lB != orig) nflag[lB] = 1;
-                    const uint64_t jmA = __ballot(joinA), jmB = __ballot(joinB);
-                    if (jmA | jmB) {
-                        if (joinA) atomicMin(&cl[jA], (uint32_t)lane);
-                        if (joinB) atomicMin(&cl[jB], 64u + (uint32_t)lane);
-                        wave_fence();
-                        const bool winA = joinA && cl[jA] == (uint32_t)lane;
-                        const bool winB = joinB && cl[jB] == 64u + (uint32_t)lane;
-                        const uint64_t wmA = __ballot(winA), wmB = __ballot(winB);
-                        const uint32_t nA = (uint32_t)__popcll((unsigned long long)wmA), nB = (uint32_t)__popcll((unsigned long long)wmB);
-                        if (maxdeg <= 8u) {
-                            if (winA) slots[qt + (uint32_t)mbcnt(wmA)] = make_uint2(jA | (djA << 16), rjA);
-                            if (winB) slots[qt + nA + (uint32_t)mbcnt(wmB)] = make_uint2(jB | (djB << 16), rjB);
-                            qt += nA + nB;
-                        } else if (maxdeg <= 16u) {
-                            const bool bigA = winA && djA > 8u, bigB = winB && djB > 8u;
-                            const uint64_t bmA = __ballot(bigA), bmB = __ballot(bigB);
-                            const uint32_t tA = nA + (uint32_t)__popcll((unsigned long long)bmA);
-                            const uint32_t baseA = qt + (uint32_t)mbcnt(wmA) + (uint32_t)mbcnt(bmA);
-                            const uint32_t baseB = qt + tA + (uint32_t)mbcnt(wmB) + (uint32_t)mbcnt(bmB);
-                            if (winA) slots[baseA] = make_uint2(jA | (min(8u, djA) << 16), rjA);
-                            if (bigA) slots[baseA + 1u] = make_uint2(jA | ((djA - 8u) << 16) | (1u << kPartShift), rjA + 8u);
-                            if (winB) slots[baseB] = make_uint2(jB | (min(8u, djB) << 16), rjB);
-                            if (bigB) slots[baseB + 1u] = make_uint2(jB | ((djB - 8u) << 16) | (1u << kPartShift), rjB + 8u);
-                            qt += tA + nB + (uint32_t)__popcll((unsigned long long)bmB);
-                        } else {
-                            const uint32_t partsA = winA ? (djA <= 8u ? 1u : (djA + 7u) >> 3) : 0u;
-                            const uint32_t partsB = winB ? (djB <= 8u ? 1u : (djB + 7u) >> 3) : 0u;
-                            const uint32_t inclA = wave_scan_add_u32(partsA), inclB = wave_scan_add_u32(partsB);
-                            const uint32_t tA = (uint32_t)__builtin_amdgcn_readlane((int)inclA, 63);
-                            const uint32_t baseA = qt + inclA - partsA, baseB = qt + tA + inclB - partsB;
-                            for (uint32_t pp = 0; pp < maxparts; ++pp) {
-                                if (pp < partsA) slots[baseA + pp] = make_uint2(jA | (min(8u, djA - 8u * pp) << 16) | (pp << kPartShift), rjA + 8u * pp);
-                                if (pp < partsB) slots[baseB + pp] = make_uint2(jB | (min(8u, djB - 8u * pp) << 16) | (pp << kPartShift), rjB + 8u * pp);
-                            }
-                            qt += tA + (uint32_t)__builtin_amdgcn_readlane((int)inclB, 63);
-                        }
-                        qn += nA + nB;
-                        queue_fence();
-                    }
-                    head += K2;
-                    if constexpr (PROF) pacc[15] += 1;
-                    continue;
+    // ---- a step = evaluate (reads the chain's state, writes only this wave's scratch) + commit (in step order) ----
+    // what an evaluation hands to the commit
+    uint32_t start = 0, orig = 0, next = 0, csize = 0, qt = 0;
+    int kase = 0, st = 0;
+    bool have1 = false, accept = false;
+    double targetL = 0.0, prop = 0.0, R2 = 0.0, R1 = 0.0;
+    SegFit f1 = { 0.0, 0, 0, 0 }, f2 = { 0.0, 0, 0, 0 };
+    double M2[kSumStride], M1[kSumStride];
+    const uint32_t g8 = (uint32_t)lane >> 3, s8 = (uint32_t)lane & 7u;
+
+    // the step's scratch (claim words of the component, neighbour flags) back to empty
+    auto cleanup = [&]() __attribute__((always_inline)) {
+        for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) cl[slots[h].x & 0xFFFFu] = kFree;
+        for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
+        wave_fence();
+    };
+
+    // commit of an evaluated step, in step order: MH bookkeeping, the jump if accepted, counters, trace
+    // scalars of the chain travel through LDS in the speculative form: loaded at the start of a wave's turn, stored at its end
+    auto load_scalars = [&]() __attribute__((always_inline)) {
+        energy = __longlong_as_double((long long)sscal[0]); best_energy = __longlong_as_double((long long)sscal[1]);
+        state_hash = sscal[2]; trace_hash = sscal[3]; n_accept = sscal[4];
+        n_case0 = sscal[5]; n_case1 = sscal[6]; n_case2 = sscal[7];
+        status = (int)(long long)sscal[8];
+        top_count = sscal[9]; top_hash = sscal[10]; overflow = sscal[11]; dwell = sscal[12];
+        last_targetL = __longlong_as_double((long long)sscal[13]); last_prop = __longlong_as_double((long long)sscal[14]);
+    };
+    auto store_scalars = [&]() __attribute__((always_inline)) {
+        if (lane == 0) {
+            sscal[0] = (unsigned long long)__double_as_longlong(energy); sscal[1] = (unsigned long long)__double_as_longlong(best_energy);
+            sscal[2] = state_hash; sscal[3] = trace_hash; sscal[4] = n_accept;
+            sscal[5] = n_case0; sscal[6] = n_case1; sscal[7] = n_case2;
+            sscal[8] = (unsigned long long)(long long)status;
+            sscal[9] = top_count; sscal[10] = top_hash; sscal[11] = overflow; sscal[12] = dwell;
+            sscal[13] = (unsigned long long)__double_as_longlong(last_targetL); sscal[14] = (unsigned long long)__double_as_longlong(last_prop);
+        }
+    };
+    constexpr uint32_t kSpinMax = 1u << 22;     // ~0.1 s of s_sleep: far beyond any step; then the chain is marked failed
+    bool failed = false;
+    unsigned long long ts_next = 0;
+    for (;;) {
+        // ---- the step this wave takes ----
+        unsigned long long ts;
+        uint32_t v0 = 0;
+        bool spec_live = false;
+        if constexpr (SPEC) {
+            uint32_t mine = 0;
+            if (lane == 0) mine = atomicAdd(const_cast<uint32_t*>(ctl), 1u);
+            ts = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+            if (ts >= total) break;
+            // a speculative evaluation needs a state that is not being rewritten (even version)
+            uint32_t spin = 0;
+            v0 = ctl[2];
+            while ((v0 & 1u) && spin < kSpinMax && ctl[3] == 0u) { __builtin_amdgcn_s_sleep(1); v0 = ctl[2]; ++spin; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            spec_live = (int)(long long)sscal[8] == 0 && !(v0 & 1u);
+        } else {
+            ts = ts_next++;
+            if (ts >= total) break;
+        }
+        const unsigned long long t = a.step0 + ts;
+        bool evaluated = false;
+        // attempt 0: evaluate now (speculatively in the two-wave form); attempt 1 (two-wave form only): at this
+        // step's turn, once more if an earlier step has changed the state meanwhile
+#pragma nounroll
+        for (int attempt = 0; attempt < (SPEC ? 2 : 1); ++attempt) {
+            bool need;
+            if constexpr (SPEC) {
+                if (attempt == 0) need = spec_live;
+                else {
+                    uint32_t spin = 0;
+                    while (ctl[1] != (uint32_t)ts && spin < kSpinMax && ctl[3] == 0u) { __builtin_amdgcn_s_sleep(1); ++spin; }
+                    if (ctl[1] != (uint32_t)ts) { failed = true; if (lane == 0) ctl[3] = 1u; break; }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    load_scalars();
+                    need = status == 0 && (!evaluated || ctl[2] != v0);
+                    if (need && evaluated) cleanup();
                 }
-                const uint32_t K = min(qt - head, 8u);
-                uint2 ent = make_uint2(0u, 0u);
-                if (g8 < K) ent = slots[head + g8];
-                const bool act = s8 < ((ent.x >> 16) & 0xFu);
-                const uint32_t e = act ? ent.y + s8 : 0u;
-                const double r = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
-                const uint32_t j = colAt(e);
-                const double qe = act ? qv[e] : -1.0;
-                const uint32_t cj = cl[j];
-                const uint32_t lj = label[j];
-                const uint32_t rj = rowp[j], dj = rowp[j + 1] - rj;
-                const bool live = !(qe < 0.0);
-                const bool fresh = live && cj == kFree;
-                const bool join = fresh && lj == orig && (r < qe);   // strict (Segmentation.cpp:110)
-                if (fresh && lj != orig) nflag[lj] = 1;
-                const uint64_t jm0 = __ballot(join);
-                if (jm0) {
-                    // several lanes may hold an open edge to the same node: the first in FIFO order takes it
-                    if (join) atomicMin(&cl[j], (uint32_t)lane);
-                    wave_fence();
-                    const bool win = join && cl[j] == (uint32_t)lane;
-                    const uint64_t wm = __ballot(win);
-                        if (maxdeg <= 8u) {
-                        if (win) slots[qt + (uint32_t)mbcnt(wm)] = make_uint2(j | (dj << 16), rj);
-                        qt += (uint32_t)__popcll((unsigned long long)wm);
-                    } else if (maxdeg <= 16u) {
-                        const bool big = win && dj > 8u;
-                        const uint64_t bm = __ballot(big);
-                        const uint32_t base = qt + (uint32_t)mbcnt(wm) + (uint32_t)mbcnt(bm);
-                        if (win) slots[base] = make_uint2(j | (min(8u, dj) << 16), rj);
-                        if (big) slots[base + 1u] = make_uint2(j | ((dj - 8u) << 16) | (1u << kPartShift), rj + 8u);
-                        qt += (uint32_t)__popcll((unsigned long long)wm) + (uint32_t)__popcll((unsigned long long)bm);
-                    } else {
-                        const uint32_t parts = win ? (dj <= 8u ? 1u : (dj + 7u) >> 3) : 0u;
-                        const uint32_t incl = wave_scan_add_u32(parts);
-                        const uint32_t base = qt + incl - parts;
-                        for (uint32_t pp = 0; pp < maxparts; ++pp)
-                            if (pp < parts) slots[base + pp] = make_uint2(j | (min(8u, dj - 8u * pp) << 16) | (pp << kPartShift), rj + 8u * pp);
-                        qt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    }
-                    qn += (uint32_t)__popcll((unsigned long long)wm);
+            } else {
+                need = status == 0;
+            }
+            if (need) {
+                g.step_lo = (uint32_t)t; g.step_hi = (uint32_t)(t >> 32);
+                const u32x4 raw0 = rng_gen(g, 0, lane);
+                // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161); the step's other
+                // scalar draws are taken out of the batch now, before the growth moves on to later positions
+                start = vlist[(uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 0) % (uint32_t)Sv];
+                const double u1 = g.buf[2];
+                const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 3);
+                const double r_mh = g.buf[4];
+                orig = label[start];
+                // the old segment's cache row (sums, probabilityL, size): in flight during the growth
+                double Co[kSegCacheUsed];
+    #pragma unroll
+                for (int k = 0; k < kSegCacheUsed; ++k) Co[k] = g_segC[(size_t)orig * kSegCacheStride + k];
+                MC_PHASE(0);
+
+                // ---- createComponent BFS (Segmentation.cpp:74-120), 8 queue slots x 8 neighbours per pass ----
+                // The reference pops one node at a time and tries its neighbours in order.  Here the FIFO is made of
+                // slots of at most 8 neighbours (a node with more takes consecutive slots), a pass takes the next 8
+                // slots, lane = 8 * slot + neighbour, and the trial of neighbour s of slot k owns the uniform at
+                // position 8 + 8 k + s (see Rng) whether or not it is needed.  A node reached through two open edges
+                // of one pass is taken by the lower lane, which is the edge the sequential loop reaches first, so the
+                // component and the FIFO order are exactly the sequential ones.
+                uint32_t qn = 1, head = 0;
+                {
+                    const uint32_t rs0 = rowp[start], d0 = rowp[start + 1] - rs0;
+                    const uint32_t parts0 = d0 <= 8u ? 1u : (d0 + 7u) >> 3;
+                    for (uint32_t pp = (uint32_t)lane; pp < parts0; pp += kWave)
+                        slots[pp] = make_uint2(start | (min(8u, d0 - 8u * pp) << 16) | (pp << kPartShift), rs0 + 8u * pp);
+                    if (lane == 0) cl[start] = 0u;
+                    qt = parts0;
                     queue_fence();
                 }
-                head += K;
-                if constexpr (PROF) pacc[15] += 1;
-            }
-            const uint32_t csize = qn;
-            const uint32_t segn_orig = (uint32_t)Co[kSegCacheN];
-            const bool same = csize == segn_orig;  // Segmentation.cpp:19
-            MC_PHASE(1);
-
-            // ---- selectSegment (Segmentation.cpp:10-57) ----
-            int kase; uint32_t next = orig; double ratio;
-            if (!same && u1 < nsp) { kase = 1; ratio = nsp; }
-            else {
-                int nnl = 0;
-                for (int w = lane; w < NWB; w += kWave) nnl += __popc(nflagw[w]);
-                const uint32_t numSeg = (uint32_t)wave_sum_i32(nnl) + 1u;
-                const double existing = same ? 1.0 : (1.0 - nsp);
-                const uint32_t idx = idx_draw % numSeg;
-                if (idx == numSeg - 1u) { kase = 0; next = orig; }
-                else { kase = 2; next = nth_flag(nflagw, NWB, idx, lane); }
-                ratio = existing / (double)numSeg;
-            }
-
-            MC_PHASE(2);
-            double targetL = 1.0, prop = ratio;  // Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic)
-            double logprop = 0.0;
-            SegFit f1 = { 0.0, 0, 0, 0 }, f2 = { 0.0, 0, 0, 0 };
-            double M2[kSumStride], M1[kSumStride], R2 = 0.0, R1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < kSumStride; ++k) { M2[k] = 0.0; M1[k] = 0.0; }
-            int st = 0;
-            const bool have1 = !same;  // sB1 = sA1 minus the component is not empty
-            if (kase != 0) {
-                // cached row of the target segment (Segment::combine / diff on sums instead of a refit from
-                // the member list, Graph.cpp:35-67): issued now, needed after the pass over the component
-                double Cn[kSegCacheUsed];
-#pragma unroll
-                for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = kase == 2 ? g_segC[(size_t)next * kSegCacheStride + k] : 0.0;
-                // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
-                // Graph.cpp:10-33), wave order over the examined-edge queue
-                double ps = 1.0, pm = 1.0;
-                // four blocks of 8 slots per trip: their LDS round trips overlap, the factors are applied in
-                // block order
-                for (uint32_t b8 = 0; b8 < qt; b8 += 32u) {
-                    uint2 ent[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t sl = b8 + 8u * (uint32_t)u + g8;
-                        ent[u] = slots[sl < qt ? sl : 0u];
-                        if (sl >= qt) ent[u].x = 0u;
+                while (head < qt) {
+                    if (!TAB_LDS && qt - head > 8u) {
+                        // Tables and FIFO behind L2 (large frames: long round trips, wide frontiers): two passes' worth
+                        // of slots (head .. head+7 = A, head+8 .. head+15 = B) in one trip, so that their round trips
+                        // overlap.  The sequential order is kept by the claim priority (A's lanes 0..63 beat B's
+                        // 64..127: a node both reach goes to A, as it would if B ran after A) and by appending A's
+                        // winners before B's.  B reads the claim words before A's claims land; the lanes that lose the
+                        // claim this way are exactly those that would have found the node taken.  Trial positions are
+                        // per slot, so the draws do not move.  (With everything in LDS this measured 5 % slower.)
+                        const uint32_t K2 = min(qt - head, 16u);
+                        const uint2 entA = slots[head + g8];
+                        uint2 entB = make_uint2(0u, 0u);
+                        if (8u + g8 < K2) entB = slots[head + 8u + g8];
+                        const bool actA = s8 < ((entA.x >> 16) & 0xFu), actB = s8 < ((entB.x >> 16) & 0xFu);
+                        const uint32_t eA = actA ? entA.y + s8 : 0u, eB = actB ? entB.y + s8 : 0u;
+                        const double rA = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
+                        const double rB = rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), lane);
+                        const uint32_t jA = colAt(eA), jB = colAt(eB);
+                        const double qA = actA ? qv[eA] : -1.0, qB = actB ? qv[eB] : -1.0;
+                        const uint32_t cA = cl[jA], cB = cl[jB];
+                        const uint32_t lA = label[jA], lB = label[jB];
+                        const uint32_t rjA = rowp[jA], djA = rowp[jA + 1] - rjA;
+                        const uint32_t rjB = rowp[jB], djB = rowp[jB + 1] - rjB;
+                        const bool freshA = !(qA < 0.0) && cA == kFree, freshB = !(qB < 0.0) && cB == kFree;
+                        const bool joinA = freshA && lA == orig && (rA < qA);
+                        const bool joinB = freshB && lB == orig && (rB < qB);
+                        if (freshA && lA != orig) nflag[lA] = 1;
+                        if (freshB && lB != orig) nflag[lB] = 1;
+                        const uint64_t jmA = __ballot(joinA), jmB = __ballot(joinB);
+                        if (jmA | jmB) {
+                            if (joinA) atomicMin(&cl[jA], (uint32_t)lane);
+                            if (joinB) atomicMin(&cl[jB], 64u + (uint32_t)lane);
+                            wave_fence();
+                            const bool winA = joinA && cl[jA] == (uint32_t)lane;
+                            const bool winB = joinB && cl[jB] == 64u + (uint32_t)lane;
+                            const uint64_t wmA = __ballot(winA), wmB = __ballot(winB);
+                            const uint32_t nA = (uint32_t)__popcll((unsigned long long)wmA), nB = (uint32_t)__popcll((unsigned long long)wmB);
+                            if (maxdeg <= 8u) {
+                                if (winA) slots[qt + (uint32_t)mbcnt(wmA)] = make_uint2(jA | (djA << 16), rjA);
+                                if (winB) slots[qt + nA + (uint32_t)mbcnt(wmB)] = make_uint2(jB | (djB << 16), rjB);
+                                qt += nA + nB;
+                            } else if (maxdeg <= 16u) {
+                                const bool bigA = winA && djA > 8u, bigB = winB && djB > 8u;
+                                const uint64_t bmA = __ballot(bigA), bmB = __ballot(bigB);
+                                const uint32_t tA = nA + (uint32_t)__popcll((unsigned long long)bmA);
+                                const uint32_t baseA = qt + (uint32_t)mbcnt(wmA) + (uint32_t)mbcnt(bmA);
+                                const uint32_t baseB = qt + tA + (uint32_t)mbcnt(wmB) + (uint32_t)mbcnt(bmB);
+                                if (winA) slots[baseA] = make_uint2(jA | (min(8u, djA) << 16), rjA);
+                                if (bigA) slots[baseA + 1u] = make_uint2(jA | ((djA - 8u) << 16) | (1u << kPartShift), rjA + 8u);
+                                if (winB) slots[baseB] = make_uint2(jB | (min(8u, djB) << 16), rjB);
+                                if (bigB) slots[baseB + 1u] = make_uint2(jB | ((djB - 8u) << 16) | (1u << kPartShift), rjB + 8u);
+                                qt += tA + nB + (uint32_t)__popcll((unsigned long long)bmB);
+                            } else {
+                                const uint32_t partsA = winA ? (djA <= 8u ? 1u : (djA + 7u) >> 3) : 0u;
+                                const uint32_t partsB = winB ? (djB <= 8u ? 1u : (djB + 7u) >> 3) : 0u;
+                                const uint32_t inclA = wave_scan_add_u32(partsA), inclB = wave_scan_add_u32(partsB);
+                                const uint32_t tA = (uint32_t)__builtin_amdgcn_readlane((int)inclA, 63);
+                                const uint32_t baseA = qt + inclA - partsA, baseB = qt + tA + inclB - partsB;
+                                for (uint32_t pp = 0; pp < maxparts; ++pp) {
+                                    if (pp < partsA) slots[baseA + pp] = make_uint2(jA | (min(8u, djA - 8u * pp) << 16) | (pp << kPartShift), rjA + 8u * pp);
+                                    if (pp < partsB) slots[baseB + pp] = make_uint2(jB | (min(8u, djB - 8u * pp) << 16) | (pp << kPartShift), rjB + 8u * pp);
+                                }
+                                qt += tA + (uint32_t)__builtin_amdgcn_readlane((int)inclB, 63);
+                            }
+                            qn += nA + nB;
+                            queue_fence();
+                        }
+                        head += K2;
+                        if constexpr (PROF) pacc[15] += 1;
+                        continue;
                     }
-                    double qe[4]; uint32_t jj[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool act = s8 < ((ent[u].x >> 16) & 0xFu);
-                        const uint32_t e = act ? ent[u].y + s8 : 0u;
-                        const double qx = qv[e];
-                        qe[u] = act ? qx : -1.0;
-                        jj[u] = colAt(e);
+                    const uint32_t K = min(qt - head, 8u);
+                    uint2 ent = make_uint2(0u, 0u);
+                    if (g8 < K) ent = slots[head + g8];
+                    const bool act = s8 < ((ent.x >> 16) & 0xFu);
+                    const uint32_t e = act ? ent.y + s8 : 0u;
+                    const double r = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
+                    const uint32_t j = colAt(e);
+                    const double qe = act ? qv[e] : -1.0;
+                    const uint32_t cj = cl[j];
+                    const uint32_t lj = label[j];
+                    const uint32_t rj = rowp[j], dj = rowp[j + 1] - rj;
+                    const bool live = !(qe < 0.0);
+                    const bool fresh = live && cj == kFree;
+                    const bool join = fresh && lj == orig && (r < qe);   // strict (Segmentation.cpp:110)
+                    if (fresh && lj != orig) nflag[lj] = 1;
+                    const uint64_t jm0 = __ballot(join);
+                    if (jm0) {
+                        // several lanes may hold an open edge to the same node: the first in FIFO order takes it
+                        if (join) atomicMin(&cl[j], (uint32_t)lane);
+                        wave_fence();
+                        const bool win = join && cl[j] == (uint32_t)lane;
+                        const uint64_t wm = __ballot(win);
+                            if (maxdeg <= 8u) {
+                            if (win) slots[qt + (uint32_t)mbcnt(wm)] = make_uint2(j | (dj << 16), rj);
+                            qt += (uint32_t)__popcll((unsigned long long)wm);
+                        } else if (maxdeg <= 16u) {
+                            const bool big = win && dj > 8u;
+                            const uint64_t bm = __ballot(big);
+                            const uint32_t base = qt + (uint32_t)mbcnt(wm) + (uint32_t)mbcnt(bm);
+                            if (win) slots[base] = make_uint2(j | (min(8u, dj) << 16), rj);
+                            if (big) slots[base + 1u] = make_uint2(j | ((dj - 8u) << 16) | (1u << kPartShift), rj + 8u);
+                            qt += (uint32_t)__popcll((unsigned long long)wm) + (uint32_t)__popcll((unsigned long long)bm);
+                        } else {
+                            const uint32_t parts = win ? (dj <= 8u ? 1u : (dj + 7u) >> 3) : 0u;
+                            const uint32_t incl = wave_scan_add_u32(parts);
+                            const uint32_t base = qt + incl - parts;
+                            for (uint32_t pp = 0; pp < maxparts; ++pp)
+                                if (pp < parts) slots[base + pp] = make_uint2(j | (min(8u, dj - 8u * pp) << 16) | (pp << kPartShift), rj + 8u * pp);
+                            qt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        }
+                        qn += (uint32_t)__popcll((unsigned long long)wm);
+                        queue_fence();
                     }
-                    uint32_t lj[4], cj[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { lj[u] = label[jj[u]]; cj[u] = cl[jj[u]]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool live = !(qe[u] < 0.0);
-                        const double w = 1.0 - qe[u];
-                        // a factor of 1.0 is exact, so the untaken edges need no branch
-                        ps = ps * ((live && lj[u] == orig && cj[u] == kFree) ? w : 1.0);
-                        pm = pm * ((live && kase == 2 && lj[u] == next && lj[u] != orig) ? w : 1.0);
+                    head += K;
+                    if constexpr (PROF) pacc[15] += 1;
+                }
+                csize = qn;
+                const uint32_t segn_orig = (uint32_t)Co[kSegCacheN];
+                const bool same = csize == segn_orig;  // Segmentation.cpp:19
+                MC_PHASE(1);
+
+                // ---- selectSegment (Segmentation.cpp:10-57) ----
+                next = orig; double ratio;
+                if (!same && u1 < nsp) { kase = 1; ratio = nsp; }
+                else {
+                    int nnl = 0;
+                    for (int w = lane; w < NWB; w += kWave) nnl += __popc(nflagw[w]);
+                    const uint32_t numSeg = (uint32_t)wave_sum_i32(nnl) + 1u;
+                    const double existing = same ? 1.0 : (1.0 - nsp);
+                    const uint32_t idx = idx_draw % numSeg;
+                    if (idx == numSeg - 1u) { kase = 0; next = orig; }
+                    else { kase = 2; next = nth_flag(nflagw, NWB, idx, lane); }
+                    ratio = existing / (double)numSeg;
+                }
+
+                MC_PHASE(2);
+                targetL = 1.0; prop = ratio;  // Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic)
+                double logprop = 0.0;
+                f1 = SegFit{ 0.0, 0, 0, 0 }; f2 = SegFit{ 0.0, 0, 0, 0 };
+                R2 = 0.0; R1 = 0.0;
+    #pragma unroll
+                for (int k = 0; k < kSumStride; ++k) { M2[k] = 0.0; M1[k] = 0.0; }
+                st = 0;
+                have1 = !same;  // sB1 = sA1 minus the component is not empty
+                if (kase != 0) {
+                    // cached row of the target segment (Segment::combine / diff on sums instead of a refit from
+                    // the member list, Graph.cpp:35-67): issued now, needed after the pass over the component
+                    double Cn[kSegCacheUsed];
+    #pragma unroll
+                    for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = kase == 2 ? g_segC[(size_t)next * kSegCacheStride + k] : 0.0;
+                    // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
+                    // Graph.cpp:10-33), wave order over the examined-edge queue
+                    double ps = 1.0, pm = 1.0;
+                    // four blocks of 8 slots per trip: their LDS round trips overlap, the factors are applied in
+                    // block order
+                    for (uint32_t b8 = 0; b8 < qt; b8 += 32u) {
+                        uint2 ent[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t sl = b8 + 8u * (uint32_t)u + g8;
+                            ent[u] = slots[sl < qt ? sl : 0u];
+                            if (sl >= qt) ent[u].x = 0u;
+                        }
+                        double qe[4]; uint32_t jj[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool act = s8 < ((ent[u].x >> 16) & 0xFu);
+                            const uint32_t e = act ? ent[u].y + s8 : 0u;
+                            const double qx = qv[e];
+                            qe[u] = act ? qx : -1.0;
+                            jj[u] = colAt(e);
+                        }
+                        uint32_t lj[4], cj[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) { lj[u] = label[jj[u]]; cj[u] = cl[jj[u]]; }
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool live = !(qe[u] < 0.0);
+                            const double w = 1.0 - qe[u];
+                            // a factor of 1.0 is exact, so the untaken edges need no branch
+                            ps = ps * ((live && lj[u] == orig && cj[u] == kFree) ? w : 1.0);
+                            pm = pm * ((live && kase == 2 && lj[u] == next && lj[u] != orig) ? w : 1.0);
+                        }
                     }
+                    // the component's sums, wave order over the FIFO slots (a node counts at its first slot)
+                    double rp = 0.0;
+                    double mc[kSumStride];
+    #pragma unroll
+                    for (int k = 0; k < kSumStride; ++k) mc[k] = 0.0;
+                    int mn = 0x7FFFFFFF;
+                    for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) {
+                        const uint32_t ex = slots[h].x;
+                        if ((ex >> kPartShift) != 0u) continue;
+                        const uint32_t i = ex & 0xFFFFu;
+    #pragma unroll
+                        for (int k = 0; k < kSumStride; ++k) mc[k] += recAt(i, k);
+                        rp += recAt(i, kSumStride);
+                        mn = min(mn, (int)i);
+                    }
+                    MC_PHASE(3);
+                    const double sep = wave_prod_f64(ps);
+                    const double mrg = kase == 2 ? wave_prod_f64(pm) : 1.0;
+    #pragma unroll
+                    for (int k = 0; k < kSumStride; ++k) mc[k] = wave_sum_f64(mc[k]);  // integer-valued: exact, order-free
+                    const double Rc = wave_sum_f64(rp);
+                    const int minC = wave_min_i32(mn);
+                    MC_PHASE(4);
+    #pragma unroll
+                    for (int k = 0; k < kSumStride; ++k) { M2[k] = kase == 2 ? Cn[k] + mc[k] : mc[k]; M1[k] = Co[k] - mc[k]; }
+                    R2 = kase == 2 ? Cn[kSumStride] + Rc : Rc;
+                    R1 = Co[kSumStride] - Rc;
+                    if (kase == 1) prop = ratio * (1.0 / sep);              // Problem.cpp:188
+                    else prop = ratio * (mrg / sep);                        // Problem.cpp:206
+                    // the two evaluations run side by side: lanes 0..31 take sB2, lanes 32..63 sB1; the three
+                    // pivot logarithms of each and log(proposal ratio) are taken by different lane groups
+                    {
+                        const bool hi = lane >= 32 && have1;   // without sB1 both halves evaluate sB2
+                        Sym3 A = { hi ? M1[0] : M2[0], hi ? M1[1] : M2[1], hi ? M1[2] : M2[2],
+                                   hi ? M1[3] : M2[3], hi ? M1[4] : M2[4], hi ? M1[5] : M2[5] };
+                        Vec3 rr = { hi ? M1[6] : M2[6], hi ? M1[7] : M2[7], hi ? M1[8] : M2[8] }, th, d;
+                        const double quad = ldl3(A, rr, th, d);
+                        const double err = (((hi ? M1[9] : M2[9]) - quad) - (hi ? R1 : R2)) / (2.0 * var);
+                        const int gg = (lane >> 3) & 3;
+                        const double lx = det_log(gg == 0 ? d.x : (gg == 1 ? d.y : (gg == 2 ? d.z : prop)));
+                        logprop = readlane_f64(lx, 24);
+                        const double logdet2 = ((readlane_f64(lx, 0) + readlane_f64(lx, 8)) + readlane_f64(lx, 16)) - 3.0 * log_var;
+                        const double logdet1 = ((readlane_f64(lx, 32) + readlane_f64(lx, 40)) + readlane_f64(lx, 48)) - 3.0 * log_var;
+                        double p2 = -readlane_f64(err, 0) + 0.5 * (3.0 * kLog2Pi - logdet2);
+                        double p1 = -readlane_f64(err, 32) + 0.5 * (3.0 * kLog2Pi - logdet1);
+                        if (p2 != p2) p2 = 0.75;                 // Graph.cpp:134
+                        if (p1 != p1) p1 = 0.75;
+                        f2.probL = p2; f2.inf_flag = (p2 - p2 != 0.0) ? 1 : 0;   // Graph.cpp:137
+                        f1.probL = have1 ? p1 : 0.0; f1.inf_flag = (have1 && p1 - p1 != 0.0) ? 1 : 0;
+                    }
+                    f2.n = (int)csize + (kase == 2 ? (int)Cn[kSegCacheN] : 0);
+                    f2.minid = (kase == 2 && (int)next < minC) ? (int)next : minC;
+                    f1.n = have1 ? (int)segn_orig - (int)csize : 0;
+                    MC_PHASE(5);
+                    // jumpProbability (Problem.cpp:475-487)
+                    const double sB2_sA1 = f2.probL - Co[kSegCacheP];
+                    const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? Cn[kSegCacheP] : 0.0);
+                    targetL = sB2_sA1 + sB1_sA2;
+                    if (f1.inf_flag || f2.inf_flag) st = -5;
+                    if (targetL != targetL || prop != prop) st = -4;        // Problem.cpp:216-217
+                    MC_PHASE(6);
                 }
-                // the component's sums, wave order over the FIFO slots (a node counts at its first slot)
-                double rp = 0.0;
-                double mc[kSumStride];
-#pragma unroll
-                for (int k = 0; k < kSumStride; ++k) mc[k] = 0.0;
-                int mn = 0x7FFFFFFF;
-                for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) {
-                    const uint32_t ex = slots[h].x;
-                    if ((ex >> kPartShift) != 0u) continue;
-                    const uint32_t i = ex & 0xFFFFu;
-#pragma unroll
-                    for (int k = 0; k < kSumStride; ++k) mc[k] += recAt(i, k);
-                    rp += recAt(i, kSumStride);
-                    mn = min(mn, (int)i);
-                }
-                MC_PHASE(3);
-                const double sep = wave_prod_f64(ps);
-                const double mrg = kase == 2 ? wave_prod_f64(pm) : 1.0;
-#pragma unroll
-                for (int k = 0; k < kSumStride; ++k) mc[k] = wave_sum_f64(mc[k]);  // integer-valued: exact, order-free
-                const double Rc = wave_sum_f64(rp);
-                const int minC = wave_min_i32(mn);
-                MC_PHASE(4);
-#pragma unroll
-                for (int k = 0; k < kSumStride; ++k) { M2[k] = kase == 2 ? Cn[k] + mc[k] : mc[k]; M1[k] = Co[k] - mc[k]; }
-                R2 = kase == 2 ? Cn[kSumStride] + Rc : Rc;
-                R1 = Co[kSumStride] - Rc;
-                if (kase == 1) prop = ratio * (1.0 / sep);              // Problem.cpp:188
-                else prop = ratio * (mrg / sep);                        // Problem.cpp:206
-                // the two evaluations run side by side: lanes 0..31 take sB2, lanes 32..63 sB1; the three
-                // pivot logarithms of each and log(proposal ratio) are taken by different lane groups
-                {
-                    const bool hi = lane >= 32 && have1;   // without sB1 both halves evaluate sB2
-                    Sym3 A = { hi ? M1[0] : M2[0], hi ? M1[1] : M2[1], hi ? M1[2] : M2[2],
-                               hi ? M1[3] : M2[3], hi ? M1[4] : M2[4], hi ? M1[5] : M2[5] };
-                    Vec3 rr = { hi ? M1[6] : M2[6], hi ? M1[7] : M2[7], hi ? M1[8] : M2[8] }, th, d;
-                    const double quad = ldl3(A, rr, th, d);
-                    const double err = (((hi ? M1[9] : M2[9]) - quad) - (hi ? R1 : R2)) / (2.0 * var);
-                    const int gg = (lane >> 3) & 3;
-                    const double lx = det_log(gg == 0 ? d.x : (gg == 1 ? d.y : (gg == 2 ? d.z : prop)));
-                    logprop = readlane_f64(lx, 24);
-                    const double logdet2 = ((readlane_f64(lx, 0) + readlane_f64(lx, 8)) + readlane_f64(lx, 16)) - 3.0 * log_var;
-                    const double logdet1 = ((readlane_f64(lx, 32) + readlane_f64(lx, 40)) + readlane_f64(lx, 48)) - 3.0 * log_var;
-                    double p2 = -readlane_f64(err, 0) + 0.5 * (3.0 * kLog2Pi - logdet2);
-                    double p1 = -readlane_f64(err, 32) + 0.5 * (3.0 * kLog2Pi - logdet1);
-                    if (p2 != p2) p2 = 0.75;                 // Graph.cpp:134
-                    if (p1 != p1) p1 = 0.75;
-                    f2.probL = p2; f2.inf_flag = (p2 - p2 != 0.0) ? 1 : 0;   // Graph.cpp:137
-                    f1.probL = have1 ? p1 : 0.0; f1.inf_flag = (have1 && p1 - p1 != 0.0) ? 1 : 0;
-                }
-                f2.n = (int)csize + (kase == 2 ? (int)Cn[kSegCacheN] : 0);
-                f2.minid = (kase == 2 && (int)next < minC) ? (int)next : minC;
-                f1.n = have1 ? (int)segn_orig - (int)csize : 0;
-                MC_PHASE(5);
-                // jumpProbability (Problem.cpp:475-487)
-                const double sB2_sA1 = f2.probL - Co[kSegCacheP];
-                const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? Cn[kSegCacheP] : 0.0);
-                targetL = sB2_sA1 + sB1_sA2;
-                if (f1.inf_flag || f2.inf_flag) st = -5;
-                if (targetL != targetL || prop != prop) st = -4;        // Problem.cpp:216-217
-                MC_PHASE(6);
+
+                MC_PHASE(7);
+                // ---- FastMetropolisHastings::iterate (MCMC.h:218-227) ----
+                if (kase == 0) logprop = det_log(prop);
+                const double aL = targetL + logprop;
+                const double acc = det_exp(aL);
+                const double r = r_mh;  // always drawn
+                accept = true;
+                if (aL < 0.0) { if (r > acc) accept = false; }
+                if (st != 0) accept = false;
+                evaluated = true;
             }
+        }
+        if constexpr (SPEC) { if (failed) break; }
 
-            MC_PHASE(7);
-            // ---- FastMetropolisHastings::iterate (MCMC.h:218-227) ----
-            if (kase == 0) logprop = det_log(prop);
-            last_targetL = targetL; last_prop = prop;
-            const double aL = targetL + logprop;
-            const double acc = det_exp(aL);
-            const double r = r_mh;  // always drawn
-            bool accept = true;
-            if (aL < 0.0) { if (r > acc) accept = false; }
-            if (st != 0) { accept = false; status = st; }
-
+        // ---- commit, in step order: MH bookkeeping, the jump if accepted, counters, trace ----
+        uint8_t tb = 0xFF;
+        if (status == 0) {
             MC_PHASE(8);
+            last_targetL = targetL; last_prop = prop;
+            if (st != 0) status = st;
             uint32_t newlab = next;
             if (accept && kase != 0) {
                 flush_stats();  // leaving the current state
+                if constexpr (SPEC) { if (lane == 0) ctl[2] = ctl[2] + 1u; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // odd: the state is being rewritten
                 MC_PHASE(9);
                 // jump (Problem.cpp:32-74) with smallest-member naming
                 const uint32_t L2 = (uint32_t)f2.minid;
@@ -728,6 +860,7 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
                     if (have1) g_segC[(size_t)L1 * kSegCacheStride + lane] = v1;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if constexpr (SPEC) { if (lane == 0) ctl[2] = ctl[2] + 1u; }                                                    // even again: a new state
                 energy += targetL;
                 if (energy > best_energy) {
                     best_energy = energy;
@@ -740,19 +873,28 @@ __global__ __launch_bounds__(WPB * 64) void chain_run_kernel(ChainArgs a, int s_
             if constexpr (PROF) { pacc[12] += csize; pacc[13] += 8ull * qt; pacc[14] += (kase != 0 ? (unsigned long long)(f1.n + f2.n) : 0ull); }
             if (accept) n_accept++;
             if (kase == 0) n_case0++; else if (kase == 1) n_case1++; else n_case2++;
-
-            // clear the step's scratch flags
-            for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) cl[slots[h].x & 0xFFFFu] = kFree;
-            for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
-            wave_fence();
-
             tb = (uint8_t)((accept ? 1 : 0) | (kase << 1));
             const uint64_t wd = (uint64_t)tb | ((uint64_t)start << 8) | ((uint64_t)csize << 24) | ((uint64_t)newlab << 40);
             trace_hash = mix64(mix64(trace_hash ^ wd) ^ state_hash);
         }
         if (a.trace && lane == 0) a.trace[(size_t)chain * a.trace_stride + ts] = tb;
         if (ts >= a.burn_in && status == 0) dwell++;
+        if (evaluated) cleanup();
+        if constexpr (SPEC) {
+            store_scalars();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (lane == 0) ctl[1] = (uint32_t)ts + 1u;
+        }
         MC_PHASE(11);
+    }
+    if constexpr (SPEC) {
+        // the chain's first wave closes the run once every step is committed
+        if (role != 0) return;
+        uint32_t spin = 0;
+        while (ctl[1] != (uint32_t)total && spin < kSpinMax && ctl[3] == 0u) { __builtin_amdgcn_s_sleep(1); ++spin; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        load_scalars();
+        if (failed || ctl[1] != (uint32_t)total) status = -2;   // MCMC_E_DEVICE: a wait ran out (never seen; a hang otherwise)
     }
     flush_stats();
     if constexpr (PROF) {
@@ -942,7 +1084,7 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int WPB, bool TAB, bool REC = TAB, bool PROF = false, bool TOPO = false>
+template <int WPB, bool TAB, bool REC = TAB, bool PROF = false, bool TOPO = false, bool SPEC = false>
 static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
 {
     if constexpr (!PROF && WPB == 4 && TAB && REC) {
@@ -951,13 +1093,13 @@ static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size
     static DeviceOnce once;
     bool* attr_done = once.slot();
     if (!attr_done || !*attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, REC, PROF, TOPO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, REC, PROF, TOPO, SPEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
         if (attr_done) *attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
-    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, REC, PROF, TOPO>), dim3(blocks), dim3(WPB * 64), bytes, st, a, s_lds, e2_lds);
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, REC, PROF, TOPO, SPEC>), dim3(blocks), dim3(WPB * 64 * (SPEC ? 2 : 1)), bytes, st, a, s_lds, e2_lds);
     return hipGetLastError();
 }
 
@@ -986,6 +1128,18 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
             if (L8.total <= cap && (a.dense_variant > 0 || a.n_chains > 4 * cus)) {
                 if (variant_out) *variant_out = 28;
                 return launch_variant<8, true, false>(a, s_used_max, e2_used_max, L8.total, st);
+            }
+        }
+    }
+    // No more chains than four per CU, i.e. at most one wave per SIMD in the plain form: two waves per chain, the
+    // second evaluating the next step speculatively (see the kernel).  Records through L2, as in the dense form.
+    if (!a.prof && a.spec_variant >= 0 && a.chains_per_frame % 4 == 0 && a.burn_in + a.iters < 0xFFFFFFFFull) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+            const LdsLayout Ls = make_layout(s_used_max, e2_used_max, 4, true, false, false, true);
+            if (Ls.total <= cap && (a.spec_variant > 0 || a.n_chains <= 4 * cus)) {
+                if (variant_out) *variant_out = 44;
+                return launch_variant<4, true, false, false, false, true>(a, s_used_max, e2_used_max, Ls.total, st);
             }
         }
     }
