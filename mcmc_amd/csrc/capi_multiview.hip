@@ -137,9 +137,12 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
     if (!c || V <= 0 || V >= 0xFFFF || !pt_ptr || !pts || !rowp || (e2 && (!col || !q)))
         return mfail(c, MCMC_E_BADARG, "mv_set_graph: bad argument");
     if (pt_ptr[0] != 0 || rowp[0] != 0 || rowp[V] != e2) return mfail(c, MCMC_E_BADARG, "mv_set_graph: offsets do not span the arrays");
+    // the whole of row_ptr first: col is only read once every row is known to lie inside [0, e2]
     for (int v = 0; v < V; ++v) {
         if (pt_ptr[v + 1] <= pt_ptr[v]) return mfail(c, MCMC_E_BADARG, "mv_set_graph: every vertex needs at least one point");
-        if (rowp[v + 1] < rowp[v]) return mfail(c, MCMC_E_BADARG, "mv_set_graph: row_ptr not monotone");
+        if (rowp[v + 1] < rowp[v] || rowp[v + 1] > e2) return mfail(c, MCMC_E_BADARG, "mv_set_graph: row_ptr not monotone");
+    }
+    for (int v = 0; v < V; ++v) {
         for (uint32_t e = rowp[v]; e < rowp[v + 1]; ++e) {
             if (col[e] >= (uint32_t)V || col[e] == (uint32_t)v) return mfail(c, MCMC_E_BADARG, "mv_set_graph: bad neighbour id");
             if (e > rowp[v] && col[e] <= col[e - 1]) return mfail(c, MCMC_E_BADARG, "mv_set_graph: neighbours must ascend");
@@ -236,6 +239,8 @@ int mcmc_mv_build_world_graph(mcmc_mv* c, int V, int dim, const float* theta, co
         if (in_row_ptr[0] != 0 || (in_e2 && !in_col)) return mfail(c, MCMC_E_BADARG, "mv_build_world_graph: bad in-view graph");
         for (int i = 0; i < V; ++i)
             if (in_row_ptr[i + 1] < in_row_ptr[i]) return mfail(c, MCMC_E_BADARG, "mv_build_world_graph: in-view row_ptr not monotone");
+        for (uint32_t e = 0; e < in_e2; ++e)
+            if (in_col[e] >= (uint32_t)V) return mfail(c, MCMC_E_BADARG, "mv_build_world_graph: in-view neighbour id out of range");
     }
     MVCHK(c, hipSetDevice(c->device));
     const int words = (V + 31) / 32;
