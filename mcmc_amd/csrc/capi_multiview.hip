@@ -19,6 +19,7 @@ struct mcmc_mv {
     int V = 0; uint32_t E2 = 0; size_t P = 0;
     float4* d_pts = nullptr; uint32_t* d_ptptr = nullptr; double* d_vm = nullptr;
     uint32_t *d_rowp = nullptr, *d_col = nullptr, *d_erank = nullptr; double* d_q = nullptr;
+    unsigned long long* d_abm = nullptr; uint32_t *d_wbase = nullptr, *d_thr = nullptr;   // bitmap form of the adjacency
     uint8_t* d_mem = nullptr; double* d_out = nullptr;
     bool have_graph = false, have_vm = false;
     // chains
@@ -57,7 +58,7 @@ template <typename T> void mvfree(T*& p) { if (p) (void)hipFree(p); p = nullptr;
 void free_graph(mcmc_mv* c)
 {
     mvfree(c->d_pts); mvfree(c->d_ptptr); mvfree(c->d_vm); mvfree(c->d_rowp); mvfree(c->d_col);
-    mvfree(c->d_erank); mvfree(c->d_q); mvfree(c->d_mem);
+    mvfree(c->d_erank); mvfree(c->d_q); mvfree(c->d_mem); mvfree(c->d_abm); mvfree(c->d_wbase); mvfree(c->d_thr);
     c->have_graph = c->have_vm = false;
 }
 void free_chains(mcmc_mv* c)
@@ -74,6 +75,7 @@ MvGraph graph_of(const mcmc_mv* c)
     MvGraph g{};
     g.V = c->V; g.pts = c->d_pts; g.pt_ptr = c->d_ptptr; g.vm = c->d_vm; g.rowp = c->d_rowp; g.col = c->d_col;
     g.q = c->d_q; g.erank = c->d_erank;
+    g.W64 = (c->V + 63) / 64; g.abm = c->d_abm; g.wbase = c->d_wbase; g.thr = c->d_thr;
     return g;
 }
 MvChainArgs chain_args_of(const mcmc_mv* c)
@@ -146,6 +148,7 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
         for (uint32_t e = rowp[v]; e < rowp[v + 1]; ++e) {
             if (col[e] >= (uint32_t)V || col[e] == (uint32_t)v) return mfail(c, MCMC_E_BADARG, "mv_set_graph: bad neighbour id");
             if (e > rowp[v] && col[e] <= col[e - 1]) return mfail(c, MCMC_E_BADARG, "mv_set_graph: neighbours must ascend");
+            if (!(q[e] >= 0.0)) return mfail(c, MCMC_E_BADARG, "mv_set_graph: BernoulliProbability must be a probability");
         }
     }
     if (mv_chain_lds_bytes(V) > 160 * 1024 - 64) return mfail(c, MCMC_E_TOO_LARGE, "mv_set_graph: per-chain state does not fit 160 KB of LDS");
@@ -165,10 +168,38 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
                 if (it == en || *it != (uint32_t)i) return mfail(c, MCMC_E_BADARG, "mv_set_graph: adjacency is not symmetric");
                 erank[e] = erank[(size_t)(it - col)];
             }
+    // the growth scan's view of the graph: a bitmap row per vertex, the entry index at which each 64-bit word's
+    // edges start (an edge's index is that plus the number of lower bits in its word: columns ascend), and the
+    // Bernoulli trial as an integer threshold: x / 4294967295.0 is monotone in x, so `u <= q`
+    // (MultiviewSegmentation.cpp:23) holds exactly for the draws x <= thr
+    const size_t W64 = ((size_t)V + 63) / 64;
+    std::vector<unsigned long long> abm((size_t)V * W64, 0ull);
+    std::vector<uint32_t> wbase((size_t)V * W64, 0u), thr(std::max<uint32_t>(e2, 1));
+    for (int v = 0; v < V; ++v) {
+        uint32_t e = rowp[v];
+        for (size_t w = 0; w < W64; ++w) {
+            wbase[(size_t)v * W64 + w] = e;
+            while (e < rowp[v + 1] && (col[e] >> 6) == w) { abm[(size_t)v * W64 + w] |= 1ull << (col[e] & 63u); ++e; }
+        }
+    }
+    for (uint32_t e = 0; e < e2; ++e) {
+        const double qe = q[e];
+        uint32_t x = 0xFFFFFFFFu;
+        if (qe < 1.0) {
+            x = (uint32_t)(qe * 4294967295.0);
+            while (x > 0u && (double)x / 4294967295.0 > qe) --x;
+            while (x < 0xFFFFFFFFu && (double)(x + 1u) / 4294967295.0 <= qe) ++x;
+        }
+        thr[e] = x;
+    }
     MVCHK(c, hipSetDevice(c->device));
     MVCHK(c, hipStreamSynchronize(c->stream));
     free_chains(c); free_graph(c);
     const size_t P = pt_ptr[V];
+    MVCHK(c, mvalloc(&c->d_abm, (size_t)V * W64)); MVCHK(c, mvalloc(&c->d_wbase, (size_t)V * W64)); MVCHK(c, mvalloc(&c->d_thr, e2));
+    MVCHK(c, hipMemcpyAsync(c->d_abm, abm.data(), (size_t)V * W64 * 8, hipMemcpyHostToDevice, c->stream));
+    MVCHK(c, hipMemcpyAsync(c->d_wbase, wbase.data(), (size_t)V * W64 * 4, hipMemcpyHostToDevice, c->stream));
+    if (e2) MVCHK(c, hipMemcpyAsync(c->d_thr, thr.data(), (size_t)e2 * 4, hipMemcpyHostToDevice, c->stream));
     MVCHK(c, mvalloc(&c->d_pts, P)); MVCHK(c, mvalloc(&c->d_ptptr, (size_t)V + 1)); MVCHK(c, mvalloc(&c->d_vm, (size_t)V * 10));
     MVCHK(c, mvalloc(&c->d_rowp, (size_t)V + 1)); MVCHK(c, mvalloc(&c->d_col, e2)); MVCHK(c, mvalloc(&c->d_erank, e2));
     MVCHK(c, mvalloc(&c->d_q, e2)); MVCHK(c, mvalloc(&c->d_mem, (size_t)V));

@@ -123,6 +123,11 @@ struct MvGraph {
     const uint32_t* col;       // [E2] ascending within a row
     const double* q;           // [E2] SPEdge::BernoulliProbability
     const uint32_t* erank;     // [E2] rank of the undirected edge among (i<j) entries
+    // the adjacency once more as bitmaps, for the growth scan of the chain step (built by mcmc_mv_set_graph)
+    int W64;                                // 64-bit words per row, (V + 63) / 64
+    const unsigned long long* abm;          // [V][W64] bit j of row v: edge (v, j)
+    const uint32_t* wbase;                  // [V][W64] entry index of the first edge of that word
+    const uint32_t* thr;                    // [E2] largest 32-bit draw x with x / 4294967295.0 <= q[e]
 };
 
 struct MvChainArgs {

@@ -27,6 +27,7 @@ namespace mc {
 constexpr uint32_t kPhiloxTagMv = 0x4D564D43u;  // "MVMC"
 constexpr int kMvWaves = 4;
 constexpr int kMvThreads = kMvWaves * 64;
+constexpr int kMvMaxV = 64 * 64;                // a bitmap row is one 64-bit word per lane (the fused kernel's LDS allows ~3.4 k vertices)
 
 struct Sym33 { double a00, a01, a02, a11, a12, a22; };
 struct Mat33 { double m[3][3]; };
@@ -394,7 +395,13 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     double* planes = a.plane + (size_t)chain * a.seg_cap * 5;
     double* segP = a.segP + (size_t)chain * a.seg_cap;
     uint8_t* pvalid = a.segP_valid + (size_t)chain * a.seg_cap;
-    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; L.se[v] = 0u; }
+    // the claim words' space holds two bitmaps here: the grown set and the union of the grown vertices' rows
+    const int W64 = g.W64;
+    unsigned long long* EB = reinterpret_cast<unsigned long long*>(L.se);
+    unsigned long long* NBU = EB + W64;
+    unsigned long long* SM = reinterpret_cast<unsigned long long*>(L.sv);   // start's segment as a bitmap, per step
+    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
+    for (int w = tid; w < 2 * W64; w += kMvThreads) EB[w] = 0ull;
     if (MODE == 2) {
         // second half: the grown set, the shared block and the residuals come from the first half and the error kernel
         for (int v = tid; v < V; v += kMvThreads) L.inE[v] = x.inE[(size_t)chain * V + v];
@@ -435,17 +442,32 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         if (MODE != 2) {
             const uint32_t start = mv_draw_at(rg, 0u) % (uint32_t)V;
             const uint16_t cs = L.cur[start];
-            if (tid == 0) { L.inE[start] = 1; L.se[start] = 1u; L.elist[0] = (uint16_t)start; sh->nE = 1u; }
+            if (tid == 0) { L.inE[start] = 1; EB[start >> 6] = 1ull << (start & 63u); L.elist[0] = (uint16_t)start; sh->nE = 1u; }
+            // The scan works on bitmap rows (MvGraph::abm): lane w of a wave holds word w of "same initial segment
+            // as start" (S) and looks at word w of a frontier vertex's row, so one trip of a wave covers all 64 x 64
+            // possible neighbours: candidates = row & S & ~set.  The words of the rows also pile up in U, from
+            // which getNeighborSegments is answered after the growth.
+            for (int bw = wave; bw < W64; bw += kMvWaves) {
+                const int j = bw * 64 + lane;
+                const unsigned long long m = __ballot(j < V && L.cur[j < V ? j : 0] == cs);
+                if (lane == 0) SM[bw] = m;
+            }
             __syncthreads();
+            const unsigned long long S = lane < W64 ? SM[lane] : 0ull;
+            unsigned long long U = 0ull;
             uint32_t* cb = L.cand + wave * 128;
             auto try_edges = [&](uint32_t e, bool valid) {
                 if (!valid) return;
                 const uint32_t j = g.col[e];
+                const uint32_t er = g.erank[e], th = g.thr[e];
                 if (L.inE[j]) return;
-                const double u = mv_unit(mv_draw_at(rg, 16u + g.erank[e]));
-                if (u <= g.q[e] && atomicExch(&L.se[j], 1u) == 0u) {          // inclusive (:23); first to claim j appends it
-                    const uint32_t idx = atomicAdd(&sh->nE, 1u);
-                    L.elist[idx] = (uint16_t)j; L.inE[j] = 1;
+                // u <= q (inclusive, :23) as draw <= threshold; the first to set j's bit appends it
+                if (mv_draw_at(rg, 16u + er) <= th) {
+                    const unsigned long long bit = 1ull << (j & 63u);
+                    if ((atomicOr(&EB[j >> 6], bit) & bit) == 0ull) {
+                        const uint32_t idx = atomicAdd(&sh->nE, 1u);
+                        L.elist[idx] = (uint16_t)j; L.inE[j] = 1;
+                    }
                 }
             };
             uint32_t head = 0, tail = 1;
@@ -453,55 +475,52 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             while (head < tail) {
                 if (MODE == 1 && a.prof && tid == 0) atomicAdd(a.prof + 8, 1ull);
                 uint32_t cn = 0;
-                // a wave's frontier vertices in turn; the CSR bounds of the next one are fetched under the
-                // scan of the current one, and up to 256 of its out-edges are loaded before any is looked at
-                uint32_t vi = head + (uint32_t)wave, r0 = 0, e1 = 0;
-                if (vi < tail) { const uint32_t v = uni((uint32_t)L.elist[vi]); r0 = uni(g.rowp[v]); e1 = uni(g.rowp[v + 1]); }
+                // a wave's frontier vertices in turn; the row of the next one is fetched under the scan of the current one
+                uint32_t vi = head + (uint32_t)wave;
+                unsigned long long aw = 0ull, naw = 0ull;
+                uint32_t wb = 0u, nwb = 0u;
+                auto fetch = [&](uint32_t at, unsigned long long& ra, uint32_t& rb) {
+                    const size_t r = (size_t)uni((uint32_t)L.elist[at]) * (size_t)W64;
+                    ra = 0ull; rb = 0u;
+                    if (lane < W64) { ra = g.abm[r + lane]; rb = g.wbase[r + lane]; }
+                };
+                if (vi < tail) fetch(vi, aw, wb);
                 while (vi < tail) {
                     const uint32_t vn = vi + (uint32_t)kMvWaves;
-                    uint32_t nr0 = 0, ne1 = 0;      // made scalar where they are used, so the fetch stays in flight
-                    if (vn < tail) { const uint32_t v = uni((uint32_t)L.elist[vn]); nr0 = g.rowp[v]; ne1 = g.rowp[v + 1]; }
-                    for (uint32_t eb = r0; eb < e1; eb += 4u * kWave) {
-                        uint32_t jj[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const uint32_t e = eb + (uint32_t)(u * kWave + lane);
-                            jj[u] = e < e1 ? g.col[e] : 0xFFFFFFFFu;
+                    if (vn < tail) fetch(vn, naw, nwb);
+                    U |= aw;
+                    unsigned long long c = aw & S;
+                    if (c) c &= ~EB[lane];
+                    // one candidate per lane and round: its entry index is the word's first plus the bits below it
+                    for (;;) {
+                        const uint64_t m = __ballot(c != 0ull);
+                        if (m == 0) break;
+                        if (c) {
+                            const int b = __ffsll((unsigned long long)c) - 1;
+                            cb[cn + (uint32_t)mbcnt(m)] = wb + (uint32_t)__popcll(aw & ((1ull << b) - 1ull));
+                            c &= c - 1ull;
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const uint32_t e0 = eb + (uint32_t)(u * kWave);
-                            if (e0 >= e1) break;
-                            const uint32_t e = e0 + (uint32_t)lane;
-                            bool cand = false;
-                            if (jj[u] != 0xFFFFFFFFu) {
-                                const uint16_t sj = L.cur[jj[u]];
-                                if (sj == cs) cand = L.inE[jj[u]] == 0;
-                                else L.nb[sj] = 1;      // getNeighborSegments (MultiviewSegmentation.cpp:112-142), same scan
-                            }
-                            const uint64_t m = __ballot(cand);
-                            if (m == 0) continue;
-                            if (cand) cb[cn + (uint32_t)mbcnt(m)] = e;
-                            cn += (uint32_t)__popcll((unsigned long long)m);
+                        cn += (uint32_t)__popcll((unsigned long long)m);
+                        wave_lds_fence();
+                        if (cn >= (uint32_t)kWave) {
+                            try_edges(cb[lane], true);
+                            const uint32_t rest = cn - (uint32_t)kWave;
+                            const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
                             wave_lds_fence();
-                            if (cn >= (uint32_t)kWave) {
-                                try_edges(cb[lane], true);
-                                const uint32_t rest = cn - (uint32_t)kWave;
-                                const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
-                                wave_lds_fence();
-                                if ((uint32_t)lane < rest) cb[lane] = keep;
-                                cn = rest;
-                                wave_lds_fence();
-                            }
+                            if ((uint32_t)lane < rest) cb[lane] = keep;
+                            cn = rest;
+                            wave_lds_fence();
                         }
                     }
-                    vi = vn; r0 = uni(nr0); e1 = uni(ne1);
+                    vi = vn; aw = naw; wb = nwb;
                 }
                 if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
                 __syncthreads();
                 head = tail; tail = uni(sh->nE);
                 __syncthreads();
             }
+            // the neighbours of the grown set, all waves together (read by wave 0 after the next barrier)
+            if (U & ~S) atomicOr(&NBU[lane], U & ~S);
             stamp(2);
             if (MODE == 1 && a.prof && tid == 0) atomicAdd(a.prof + 9, (unsigned long long)sh->nE);
             if (tid == 0) {
@@ -521,7 +540,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         if (kind == 3) {
             if (MODE == 2) break;                  // frozen and traced by the first half
             status = -6;
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) { L.inE[L.elist[i]] = 0; L.se[L.elist[i]] = 0u; }
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
+            for (int w = tid; w < 2 * W64; w += kMvThreads) EB[w] = 0ull;
             if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
             if (MODE == 1) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
             __syncthreads();
@@ -540,9 +560,20 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             if (tid == 0) pvalid[tg] = 0;
             nseg++; n_split++;
         } else {
-            // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids: marked by the growth scan,
-            // which visits every out-edge of every grown vertex once
+            // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids, from the rows the growth
+            // scan has seen (every grown vertex's row exactly once)
             if (wave == 0) {
+                // the initial ids of the neighbouring vertices (NBU: every neighbour of the set outside start's segment)
+                for (int w0 = 0; w0 < W64; w0 += kWave) {
+                    const int w = w0 + lane;
+                    unsigned long long u = w < W64 ? NBU[w] : 0ull;
+                    while (u) {
+                        const int b = __ffsll((unsigned long long)u) - 1;
+                        L.nb[L.cur[w * 64 + b]] = 1;
+                        u &= u - 1ull;
+                    }
+                }
+                wave_lds_fence();
                 int nn = 0;
                 for (int b = 0; b < V; b += kWave) {
                     const int s = b + lane;
@@ -617,7 +648,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
             if (MODE == 1) {
-                int prof_pts = 0, prof_ev = 0;
+                int prof_pts = 0, prof_ev = 0, prof_pe = 0;
                 for (int v = tid; v < V; v += kMvThreads) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
@@ -629,11 +660,15 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                         // points of SB1 u SB2 (the algorithmic-bytes figure of SURVEY 8d) and evaluations asked for
                         prof_pts += (int)(g.pt_ptr[v + 1] - g.pt_ptr[v]);
                         prof_ev += __popc(nb4);
+                        prof_pe += __popc(nb4) * (int)(g.pt_ptr[v + 1] - g.pt_ptr[v]);   // residuals |n.p + d| asked for
                     }
                 }
                 if (a.prof) {
-                    prof_pts = wave_sum_i32(prof_pts); prof_ev = wave_sum_i32(prof_ev);
-                    if (lane == 0) { atomicAdd(a.prof + 10, (unsigned long long)prof_pts); atomicAdd(a.prof + 11, (unsigned long long)prof_ev); }
+                    prof_pts = wave_sum_i32(prof_pts); prof_ev = wave_sum_i32(prof_ev); prof_pe = wave_sum_i32(prof_pe);
+                    if (lane == 0) {
+                        atomicAdd(a.prof + 10, (unsigned long long)prof_pts); atomicAdd(a.prof + 11, (unsigned long long)prof_ev);
+                        atomicAdd(a.prof + 12, (unsigned long long)prof_pe);
+                    }
                 }
             }
             if (MODE == 0)
@@ -703,7 +738,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         }
         // clear the step's flags (the halves of a split step start from cleared LDS instead)
         if (MODE == 0) {
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) { L.inE[L.elist[i]] = 0; L.se[L.elist[i]] = 0u; }
+            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
+            for (int w = tid; w < 2 * W64; w += kMvThreads) EB[w] = 0ull;
             for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
         }
         __syncthreads();
@@ -986,6 +1022,7 @@ hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream
 {
     hipError_t e = mv_set_lds_attr();
     if (e != hipSuccess) return e;
+    if (g.V > kMvMaxV) return hipErrorInvalidValue;
     const size_t bytes = mv_lds_bytes(g.V, true);
     if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
     MvExchange x{};
@@ -999,6 +1036,7 @@ size_t mv_exchange_shared_bytes() { return sizeof(MvShared); }
 hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, void* ex_sh, uint8_t* ex_inE, uint8_t* ex_need,
                                      double* ex_err, hipStream_t st)
 {
+    if (g.V > kMvMaxV) return hipErrorInvalidValue;
     hipError_t e = mv_set_lds_attr();
     if (e != hipSuccess) return e;
     const size_t bytes = mv_lds_bytes(g.V, false);

@@ -217,6 +217,43 @@ def test_gpu_chains_bit_exact(gpu_mv, mv_small, split_prob):
 
 
 @pytest.mark.gpu
+def test_gpu_edge_trial_thresholds(gpu_mv, mv_small):
+    """The kernel tries an edge as `draw <= threshold` (integers) where the oracle compares draw / 4294967295.0
+    with BernoulliProbability (MultiviewSegmentation.cpp:23): probabilities at and next to representable
+    draws, 0, 1, above 1 and denormal-small must give the same chains."""
+    import dataclasses
+    mv = mv_small
+    rng = np.random.default_rng(12)
+    src = np.repeat(np.arange(mv.n_vertices), np.diff(mv.row_ptr.astype(np.int64)))
+    key = np.minimum(src, mv.col).astype(np.int64) * mv.n_vertices + np.maximum(src, mv.col)
+    _, und = np.unique(key, return_inverse=True)                   # both directions of an edge share a value
+    x = rng.integers(0, 2**32, und.max() + 1, dtype=np.uint64).astype(np.float64)
+    exact = x / 4294967295.0
+    pool = np.stack([exact, np.nextafter(exact, 0.0), np.nextafter(exact, 2.0), np.zeros_like(x), np.ones_like(x),
+                     np.full_like(x, 1.5), np.full_like(x, 5e-324), rng.uniform(0, 1, x.size)])
+    q = pool[rng.integers(0, pool.shape[0], x.size), np.arange(x.size)][und]
+    q = np.maximum(q, 0.0)
+    mv2 = dataclasses.replace(mv, q=q)
+    _load(gpu_mv, mv2)
+    n, steps = 5, 60
+    gpu_mv.chains_init(n, seed=21, max_new_segments=64, split_prob=0.2)
+    gpu_mv.chains_set_trace(steps)
+    orc = O.MvChains(mv2, n, seed=21, max_new_segments=64, split_prob=0.2)
+    assert np.array_equal(gpu_mv.labels(0), orc.labels(0))
+    gpu_mv.chains_run(steps)
+    of, oa = orc.run(steps)
+    gf, ga = gpu_mv.trace()
+    assert np.array_equal(gf, of) and np.array_equal(ga.view(np.uint64), oa.view(np.uint64))
+    assert np.array_equal(gpu_mv.scalars()["trace_hash"], orc.scalars()["trace_hash"])
+    # not a probability: refused (a negative or NaN value could never succeed; the reference's are exp(-d/T))
+    for bad in (-1e-9, np.nan):
+        qb = q.copy(); qb[3] = bad
+        with pytest.raises(Exception):
+            gpu_mv.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, qb)
+    _load(gpu_mv, mv)
+
+
+@pytest.mark.gpu
 def test_gpu_chains_capacity_overflow(gpu_mv, mv_small):
     _load(gpu_mv, mv_small)
     gpu_mv.chains_init(2, seed=1, max_new_segments=1, split_prob=1.0)
