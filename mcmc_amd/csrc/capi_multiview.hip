@@ -18,8 +18,9 @@ struct mcmc_mv {
     std::string err;
     int V = 0; uint32_t E2 = 0; size_t P = 0;
     float4* d_pts = nullptr; uint32_t* d_ptptr = nullptr; double* d_vm = nullptr;
-    uint32_t *d_rowp = nullptr, *d_col = nullptr, *d_erank = nullptr; double* d_q = nullptr;
-    unsigned long long* d_abm = nullptr; uint32_t *d_wbase = nullptr, *d_thr = nullptr;   // bitmap form of the adjacency
+    uint32_t *d_rowp = nullptr, *d_col = nullptr; uint2* d_et = nullptr; double* d_q = nullptr;
+    unsigned long long* d_abm = nullptr; uint32_t* d_wbase = nullptr;   // bitmap form of the adjacency
+    double* d_ptsd = nullptr; uint32_t* d_vorder = nullptr;                               // points as doubles in wave order
     uint8_t* d_mem = nullptr; double* d_out = nullptr;
     bool have_graph = false, have_vm = false;
     // chains
@@ -31,6 +32,7 @@ struct mcmc_mv {
     uint8_t* trace = nullptr; double* trace_a = nullptr;
     // split step: exchange buffers between the two halves of an iteration and the error kernel
     void* ex_sh = nullptr; uint8_t *ex_inE = nullptr, *ex_need = nullptr; double* ex_err = nullptr;
+    uint16_t* ex_plist = nullptr; uint2* ex_queue = nullptr; uint32_t* ex_counters = nullptr;
     int opt_split = -1;   // -1 automatic (split from 32 chains on), 0 fused, 1 split
     int opt_prof = 0;
     unsigned long long* d_prof = nullptr;
@@ -58,7 +60,8 @@ template <typename T> void mvfree(T*& p) { if (p) (void)hipFree(p); p = nullptr;
 void free_graph(mcmc_mv* c)
 {
     mvfree(c->d_pts); mvfree(c->d_ptptr); mvfree(c->d_vm); mvfree(c->d_rowp); mvfree(c->d_col);
-    mvfree(c->d_erank); mvfree(c->d_q); mvfree(c->d_mem); mvfree(c->d_abm); mvfree(c->d_wbase); mvfree(c->d_thr);
+    mvfree(c->d_et); mvfree(c->d_q); mvfree(c->d_mem); mvfree(c->d_abm); mvfree(c->d_wbase);
+    mvfree(c->d_ptsd); mvfree(c->d_vorder);
     c->have_graph = c->have_vm = false;
 }
 void free_chains(mcmc_mv* c)
@@ -68,14 +71,16 @@ void free_chains(mcmc_mv* c)
     mvfree(c->trace); mvfree(c->trace_a);
     { uint8_t* p = static_cast<uint8_t*>(c->ex_sh); mvfree(p); c->ex_sh = nullptr; }
     mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err); mvfree(c->d_prof);
+    mvfree(c->ex_plist); mvfree(c->ex_queue); mvfree(c->ex_counters);
     c->n = 0; c->trace_cap = 0; c->last_steps = 0;
 }
 MvGraph graph_of(const mcmc_mv* c)
 {
     MvGraph g{};
     g.V = c->V; g.pts = c->d_pts; g.pt_ptr = c->d_ptptr; g.vm = c->d_vm; g.rowp = c->d_rowp; g.col = c->d_col;
-    g.q = c->d_q; g.erank = c->d_erank;
-    g.W64 = (c->V + 63) / 64; g.abm = c->d_abm; g.wbase = c->d_wbase; g.thr = c->d_thr;
+    g.q = c->d_q; g.et = c->d_et;
+    g.W64 = (c->V + 63) / 64; g.abm = c->d_abm; g.wbase = c->d_wbase;
+    g.ptsd = c->d_ptsd; g.vorder = c->d_vorder;
     return g;
 }
 MvChainArgs chain_args_of(const mcmc_mv* c)
@@ -174,7 +179,8 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
     // (MultiviewSegmentation.cpp:23) holds exactly for the draws x <= thr
     const size_t W64 = ((size_t)V + 63) / 64;
     std::vector<unsigned long long> abm((size_t)V * W64, 0ull);
-    std::vector<uint32_t> wbase((size_t)V * W64, 0u), thr(std::max<uint32_t>(e2, 1));
+    std::vector<uint32_t> wbase((size_t)V * W64, 0u);
+    std::vector<uint2> et(std::max<uint32_t>(e2, 1));
     for (int v = 0; v < V; ++v) {
         uint32_t e = rowp[v];
         for (size_t w = 0; w < W64; ++w) {
@@ -190,18 +196,32 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
             while (x > 0u && (double)x / 4294967295.0 > qe) --x;
             while (x < 0xFFFFFFFFu && (double)(x + 1u) / 4294967295.0 <= qe) ++x;
         }
-        thr[e] = x;
+        et[e].x = erank[e]; et[e].y = x;
     }
+    // the L1 pass's view of the points (mv_errors_kernel): doubles (x, y, z, 1), and the vertices by descending
+    // point count
+    const size_t P = pt_ptr[V];
+    std::vector<double> ptsd((P + 16) * 4, 0.0);
+    for (size_t i = 0; i < P; ++i) {
+        ptsd[i * 4] = (double)pts[i * 4]; ptsd[i * 4 + 1] = (double)pts[i * 4 + 1]; ptsd[i * 4 + 2] = (double)pts[i * 4 + 2];
+        ptsd[i * 4 + 3] = 1.0;
+    }
+    std::vector<uint32_t> vorder((size_t)V);
+    for (int v = 0; v < V; ++v) vorder[(size_t)v] = (uint32_t)v;
+    std::stable_sort(vorder.begin(), vorder.end(), [&](uint32_t a, uint32_t b2) {
+        return pt_ptr[a + 1] - pt_ptr[a] > pt_ptr[b2 + 1] - pt_ptr[b2]; });
     MVCHK(c, hipSetDevice(c->device));
     MVCHK(c, hipStreamSynchronize(c->stream));
     free_chains(c); free_graph(c);
-    const size_t P = pt_ptr[V];
-    MVCHK(c, mvalloc(&c->d_abm, (size_t)V * W64)); MVCHK(c, mvalloc(&c->d_wbase, (size_t)V * W64)); MVCHK(c, mvalloc(&c->d_thr, e2));
+    MVCHK(c, mvalloc(&c->d_ptsd, (P + 16) * 4)); MVCHK(c, mvalloc(&c->d_vorder, (size_t)V));
+    MVCHK(c, hipMemcpyAsync(c->d_ptsd, ptsd.data(), (P + 16) * 32, hipMemcpyHostToDevice, c->stream));
+    MVCHK(c, hipMemcpyAsync(c->d_vorder, vorder.data(), (size_t)V * 4, hipMemcpyHostToDevice, c->stream));
+    MVCHK(c, mvalloc(&c->d_abm, (size_t)V * W64)); MVCHK(c, mvalloc(&c->d_wbase, (size_t)V * W64)); MVCHK(c, mvalloc(&c->d_et, e2));
     MVCHK(c, hipMemcpyAsync(c->d_abm, abm.data(), (size_t)V * W64 * 8, hipMemcpyHostToDevice, c->stream));
     MVCHK(c, hipMemcpyAsync(c->d_wbase, wbase.data(), (size_t)V * W64 * 4, hipMemcpyHostToDevice, c->stream));
-    if (e2) MVCHK(c, hipMemcpyAsync(c->d_thr, thr.data(), (size_t)e2 * 4, hipMemcpyHostToDevice, c->stream));
+    if (e2) MVCHK(c, hipMemcpyAsync(c->d_et, et.data(), (size_t)e2 * 8, hipMemcpyHostToDevice, c->stream));
     MVCHK(c, mvalloc(&c->d_pts, P)); MVCHK(c, mvalloc(&c->d_ptptr, (size_t)V + 1)); MVCHK(c, mvalloc(&c->d_vm, (size_t)V * 10));
-    MVCHK(c, mvalloc(&c->d_rowp, (size_t)V + 1)); MVCHK(c, mvalloc(&c->d_col, e2)); MVCHK(c, mvalloc(&c->d_erank, e2));
+    MVCHK(c, mvalloc(&c->d_rowp, (size_t)V + 1)); MVCHK(c, mvalloc(&c->d_col, e2));
     MVCHK(c, mvalloc(&c->d_q, e2)); MVCHK(c, mvalloc(&c->d_mem, (size_t)V));
     MVCHK(c, hipMemcpyAsync(c->d_pts, pts, P * 16, hipMemcpyHostToDevice, c->stream));
     MVCHK(c, hipMemcpyAsync(c->d_ptptr, pt_ptr, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, c->stream));
@@ -209,7 +229,6 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
     if (e2) {
         MVCHK(c, hipMemcpyAsync(c->d_col, col, (size_t)e2 * 4, hipMemcpyHostToDevice, c->stream));
         MVCHK(c, hipMemcpyAsync(c->d_q, q, (size_t)e2 * 8, hipMemcpyHostToDevice, c->stream));
-        MVCHK(c, hipMemcpyAsync(c->d_erank, erank.data(), (size_t)e2 * 4, hipMemcpyHostToDevice, c->stream));
     }
     MVCHK(c, hipStreamSynchronize(c->stream));
     c->V = V; c->E2 = e2; c->P = P; c->have_graph = true;
@@ -396,6 +415,9 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         uint8_t* shp = nullptr;
         MVCHK(c, mvalloc(&shp, N * mv_exchange_shared_bytes())); c->ex_sh = shp;
         MVCHK(c, mvalloc(&c->ex_inE, NV)); MVCHK(c, mvalloc(&c->ex_need, NV)); MVCHK(c, mvalloc(&c->ex_err, NV * 4));
+        MVCHK(c, mvalloc(&c->ex_plist, mv_split_plist_entries(c->V, c->n))); MVCHK(c, mvalloc(&c->ex_queue, mv_split_queue_entries(c->V, c->n)));
+        MVCHK(c, mvalloc(&c->ex_counters, 2));
+        MVCHK(c, hipMemsetAsync(c->ex_counters, 0, 2 * sizeof(uint32_t), c->stream));
     }
     if (c->opt_prof) {
         if (!c->d_prof) MVCHK(c, mvalloc(&c->d_prof, 16));
@@ -403,7 +425,10 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         a.prof = c->d_prof;
     }
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (split) MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->stream));
+    if (split) {
+        const MvSplitBufs bufs{ c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->ex_plist, c->ex_queue, c->ex_counters };
+        MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, bufs, c->stream));
+    }
     else MVCHK(c, launch_mv_chain_run(graph_of(c), a, c->stream));
     MVCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;

@@ -122,12 +122,16 @@ struct MvGraph {
     const uint32_t* rowp;      // [V+1]
     const uint32_t* col;       // [E2] ascending within a row
     const double* q;           // [E2] SPEdge::BernoulliProbability
-    const uint32_t* erank;     // [E2] rank of the undirected edge among (i<j) entries
+    const uint2* et;           // [E2] .x rank of the undirected edge among (i<j) entries (the trial's draw index),
+                               //      .y largest 32-bit draw x with x / 4294967295.0 <= q[e]: one load per trial
     // the adjacency once more as bitmaps, for the growth scan of the chain step (built by mcmc_mv_set_graph)
     int W64;                                // 64-bit words per row, (V + 63) / 64
     const unsigned long long* abm;          // [V][W64] bit j of row v: edge (v, j)
     const uint32_t* wbase;                  // [V][W64] entry index of the first edge of that word
-    const uint32_t* thr;                    // [E2] largest 32-bit draw x with x / 4294967295.0 <= q[e]
+    // the points once more for the L1 pass of the split iteration (built by mcmc_mv_set_graph): doubles, four per
+    // point (x, y, z, 1): a row of the A operand of v_mfma_f64_16x16x4_f64; 16 points of padding at the end
+    const double* ptsd;                     // [P + 16][4]
+    const uint32_t* vorder;                 // [V] vertex ids by descending point count
 };
 
 struct MvChainArgs {
@@ -151,8 +155,14 @@ hipError_t launch_mv_vertex_moments(const MvGraph& g, double* out, hipStream_t s
 hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* out, hipStream_t st);
 hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
-hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a, void* ex_sh, uint8_t* ex_inE, uint8_t* ex_need,
-                                     double* ex_err, hipStream_t st);
+// device buffers of the split iteration (capi_multiview.hip allocates them; sizes from the functions below)
+struct MvSplitBufs {
+    void* sh; uint8_t* inE; uint8_t* need; double* err;     // [C] shared blocks, [C][V], [V][C], [C][4][V]
+    uint16_t* plist; uint2* queue; uint32_t* counters;      // mv_split_plist_entries, mv_split_queue_entries, [2] zeroed once
+};
+size_t mv_split_plist_entries(int V, int n_chains);
+size_t mv_split_queue_entries(int V, int n_chains);
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a, const MvSplitBufs& bufs, hipStream_t st);
 size_t mv_exchange_shared_bytes();
 size_t mv_chain_lds_bytes(int V);
 hipError_t launch_mv_world_bits(const float* th, const float* w, int dim, int V, int n0, const uint32_t* in_rowp,

@@ -97,16 +97,37 @@ MC_HD double prob_from_error(double err, double det)
 }
 
 // mean |n.p + d| over the points of vertex v, wave order (one wave, all lanes return it)
+// The residual of one point: the chain fma(d, 1, fma(nz, z, fma(ny, y, fma(nx, x, 0)))), bit for bit what
+// v_mfma_f64_16x16x4_f64 makes of a row of four products added to C = 0 (tools/micro/mfma_f64_probe.hip), so
+// that the matrix-core form of the L1 pass (mv_errors_kernel) and this one agree.
+MC_D double point_residual(double nx, double ny, double nz, double d0, double x, double y, double z)
+{
+    double d = __builtin_fma(x, nx, 0.0);
+    d = __builtin_fma(y, ny, d);
+    d = __builtin_fma(z, nz, d);
+    return __builtin_fma(1.0, d0, d);
+}
+// 64 partial sums m = 16 q + 4 r + g, one per lane, combined over r, then q, then g (see mv_errors_kernel: r sits in
+// the registers of a lane there, q in passes, g across the rows of the wave); every lane ends with the same bits
+MC_D double vertex_tree_sum(double v)
+{
+    v = v + __shfl_xor(v, 4, kWave);
+    v = v + __shfl_xor(v, 8, kWave);
+    v = v + __shfl_xor(v, 16, kWave);
+    v = v + __shfl_xor(v, 32, kWave);
+    v = v + __shfl_xor(v, 1, kWave);
+    v = v + __shfl_xor(v, 2, kWave);
+    return v;
+}
 MC_D double vertex_error(const float4* pts, uint32_t b, uint32_t e, const double* pl, int lane)
 {
     const double nx = pl[0], ny = pl[1], nz = pl[2], d0 = pl[3];
     double part = 0.0;
     for (uint32_t i = b + (uint32_t)lane; i < e; i += kWave) {
         const float4 p = pts[i];
-        const double d = (((nx * (double)p.x) + (ny * (double)p.y)) + (nz * (double)p.z)) + d0;
-        part += d < 0.0 ? -d : d;
+        part += __builtin_fabs(point_residual(nx, ny, nz, d0, (double)p.x, (double)p.y, (double)p.z));
     }
-    return wave_sum_f64(part) / (double)(e - b);
+    return vertex_tree_sum(part) / (double)(e - b);
 }
 
 __global__ __launch_bounds__(256) void mv_vertex_moments_kernel(MvGraph g, double* out)
@@ -244,7 +265,7 @@ struct MvLds {
     uint16_t *cur, *own, *elist, *sv;
     uint8_t *inE, *nb;
     uint32_t* se;       // [V] claim words of the growth (0 = free)
-    uint32_t* cand;     // [4][128] candidate edges per wave
+    uint32_t* cand;     // [4][256] words: candidate edges per wave (init: 128 entry indices; run: 128 (entry, neighbour) pairs)
     double* errv;       // [4][V]
     MvShared* sh;
 };
@@ -254,7 +275,7 @@ struct MvLds {
 __host__ __device__ inline size_t mv_lds_bytes(int V, bool with_err)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return A(sizeof(MvShared)) + 2048 + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
+    return A(sizeof(MvShared)) + 4096 + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
 }
 
 MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
@@ -263,7 +284,7 @@ MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
     MvLds L;
     size_t o = 0;
     L.sh = reinterpret_cast<MvShared*>(smem + o); o += A(sizeof(MvShared));
-    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += 2048;
+    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += 4096;
     L.errv = reinterpret_cast<double*>(smem + o); if (with_err) o += A((size_t)V * 32);
     L.se = reinterpret_cast<uint32_t*>(smem + o); o += A((size_t)V * 4);
     L.cur = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
@@ -293,7 +314,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
         // vertices in turn, collects the out-edges to unlabelled vertices and tries them 64 at a time; a
         // vertex is claimed with atomicExch on its claim word.
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, 0xFFFFFFFFu, 0xFFFFFFFFu };
-        uint32_t* cb = L.cand + wave * 128;
+        uint32_t* cb = L.cand + wave * 256;
         int ncomp = 0;
         for (int s0 = 0; s0 < V; ++s0) {
             if (L.cur[s0] != 0xFFFFu) continue;      // uniform over the workgroup (LDS value, read after a barrier)
@@ -304,9 +325,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
                 if (!valid) return;
                 const uint32_t j = g.col[e];
                 if (L.cur[j] != 0xFFFFu) return;
-                const uint32_t er = g.erank[e];
-                const double qe = g.q[e];
-                if (mv_unit(mv_draw_at(rg, er)) <= qe && atomicExch(&L.se[j], 1u) == 0u) {   // inclusive (:23)
+                const uint2 t = g.et[e];
+                if (mv_draw_at(rg, t.x) <= t.y && atomicExch(&L.se[j], 1u) == 0u) {   // u <= q, inclusive (:23), as draw <= threshold
                     const uint32_t idx = atomicAdd(&L.sh->nE, 1u);
                     L.elist[idx] = (uint16_t)j; L.cur[j] = (uint16_t)ncomp;
                 }
@@ -373,6 +393,9 @@ struct MvExchange {
     uint8_t* inE;       // [C][V] the grown set
     uint8_t* need;      // [V][C] bit k: the L1 residual of vertex v under plane k of this chain is wanted
     double* err;        // [C][4][V]
+    uint16_t* plist;    // [chain blocks][V][4096] the pairs (chain in block << 2 | plane) that want a vertex's residual
+    uint2* queue;       // [chain blocks * V * 64] items of 64 pairs: .x vertex | chain block << 16, .y item | pairs << 8
+    uint32_t* counters; // [0] queue length: counted up by mv_err_pairs_kernel, cleared by the second half
 };
 
 // PatternedMatcher.cpp:58-130.  MODE 0: `steps` whole iterations per launch, one workgroup per chain, the L1
@@ -409,6 +432,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         uint32_t* dst = reinterpret_cast<uint32_t*>(sh);
         for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += kMvThreads) dst[k] = src[k];
         L.errv = x.err + (size_t)chain * 4 * V;
+        if (chain == 0 && tid == 0) x.counters[0] = 0u;     // the error kernel has drained the queue: empty for the next iteration
     }
     int nseg = a.nseg[chain], status = a.status[chain];
     unsigned long long n_accept = a.n_accept[chain], n_split = a.n_split[chain], n_skip = a.n_skip[chain];
@@ -455,14 +479,14 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             __syncthreads();
             const unsigned long long S = lane < W64 ? SM[lane] : 0ull;
             unsigned long long U = 0ull;
-            uint32_t* cb = L.cand + wave * 128;
-            auto try_edges = [&](uint32_t e, bool valid) {
+            uint2* cb = reinterpret_cast<uint2*>(L.cand + wave * 256);
+            auto try_edges = [&](uint2 ej, bool valid) {
                 if (!valid) return;
-                const uint32_t j = g.col[e];
-                const uint32_t er = g.erank[e], th = g.thr[e];
+                const uint2 t = g.et[ej.x];          // the trial's draw index and threshold: the one global load of a trial
+                const uint32_t j = ej.y;
                 if (L.inE[j]) return;
                 // u <= q (inclusive, :23) as draw <= threshold; the first to set j's bit appends it
-                if (mv_draw_at(rg, 16u + er) <= th) {
+                if (mv_draw_at(rg, 16u + t.x) <= t.y) {
                     const unsigned long long bit = 1ull << (j & 63u);
                     if ((atomicOr(&EB[j >> 6], bit) & bit) == 0ull) {
                         const uint32_t idx = atomicAdd(&sh->nE, 1u);
@@ -497,7 +521,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                         if (m == 0) break;
                         if (c) {
                             const int b = __ffsll((unsigned long long)c) - 1;
-                            cb[cn + (uint32_t)mbcnt(m)] = wb + (uint32_t)__popcll(aw & ((1ull << b) - 1ull));
+                            cb[cn + (uint32_t)mbcnt(m)] = make_uint2(wb + (uint32_t)__popcll(aw & ((1ull << b) - 1ull)), (uint32_t)(lane * 64 + b));
                             c &= c - 1ull;
                         }
                         cn += (uint32_t)__popcll((unsigned long long)m);
@@ -505,7 +529,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                         if (cn >= (uint32_t)kWave) {
                             try_edges(cb[lane], true);
                             const uint32_t rest = cn - (uint32_t)kWave;
-                            const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
+                            const uint2 keep = (uint32_t)lane < rest ? cb[kWave + lane] : make_uint2(0u, 0u);
                             wave_lds_fence();
                             if ((uint32_t)lane < rest) cb[lane] = keep;
                             cn = rest;
@@ -752,97 +776,167 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     }
 }
 
-// L1 residuals of one split step: wave = (vertex, block of chains).  The wave reads which chains want the vertex
-// (64 codes per load, chain-minor layout), and for every wanted (chain, plane) runs the same per-vertex loop
-// as the fused kernel -- the vertex's points stay in L1 / L2 for all of them.
-constexpr int kErrChainsPerBlock = 64;   // one wave = (vertex, 64 chains): fine-grained, the need for a vertex is very uneven
-constexpr int kErrRegPts = 10;      // points per lane held in registers as doubles (640 per vertex); the rest is re-read
-// The evaluations of one wave for NF full rows of 64 points in registers (+ one partial row, + the points past
-// the registers): straight-line arithmetic per evaluation, so the rows' products overlap and only the NF adds
-// into `part` are a chain.  |d| as fabs: it differs from `d < 0 ? -d : d` only in the sign of a zero or a NaN,
-// neither of which changes `part` as a value (a NaN residual ends as probability 0, MultiviewSegment.cpp:86-91).
-template <int NF>
-MC_D void err_block(const MvGraph& g, int n_chains, const MvExchange& x, int v, int c0, int c1, uint32_t b, uint32_t e,
-                    const double (&px)[kErrRegPts], const double (&py)[kErrRegPts], const double (&pz)[kErrRegPts], int lane)
+// L1 residuals of one split step, two kernels.
+//
+// mv_err_pairs_kernel: a wave takes a vertex, packs the (chain, plane) pairs that want the vertex's residual into a
+// list and cuts it into items of up to 64 pairs; the items of a workgroup's 16 vertices go to a queue with one
+// atomic (vertices with many points come first, so the queue is roughly by descending cost).
+//
+// mv_errors_kernel: a wave takes items i, i + waves, ...  The residuals of 16 points under 16 planes are one
+// v_mfma_f64_16x16x4_f64: A = the points (row = point, k = x y z 1), B = the planes (k = nx ny nz d, column = pair),
+// C = 0; the instruction adds the four products of a row as a chain of FMAs in k order, which is the definition of
+// the residual (point_residual above, and the oracle).  Lane l holds column l % 16 (a pair) and rows 4 r + l / 16
+// (points) in its four result registers r, so |.| is added with plain vector adds, lane by lane, into the partial
+// sums by point index mod 64: m = 16 q + 4 r + g with q = block mod 4 (one pass over the blocks per q), r the
+// register, g = l / 16.  The tree over r and q needs no data movement, the one over g is two cross-row exchanges
+// per group of 16 pairs and item.  Up to four groups of 16 pairs share the points of an item.
+constexpr int kErrChainsPerBlock = 1024;
+constexpr int kErrItemsPerBlock = kErrChainsPerBlock * 4 / kWave;      // at most 64 items per (vertex, chain block)
+constexpr int kErrVertsPerGroup = 16;                                  // vertices per workgroup of mv_err_pairs_kernel
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel(MvGraph g, int n_chains, MvExchange x)
 {
-    const uint32_t cnt = e - b;
-    const double dn = (double)cnt;
-    const bool tail = NF < kErrRegPts && (uint32_t)(NF * kWave + lane) < cnt;
-    for (int cb = c0; cb < c1; cb += kWave) {
-        const int cc = cb + lane;
-        const uint32_t code = cc < c1 ? (uint32_t)x.need[(size_t)v * n_chains + cc] : 0u;
-        if (!__ballot(code != 0u)) continue;
-        const MvShared* shc = x.sh + (cc < c1 ? cc : c0);
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const bool want = ((code >> k) & 1u) != 0u;
-            uint64_t m = __ballot(want);
-            if (!m) continue;
-            // every lane fetches the plane of its own chain; the evaluations below broadcast them lane by lane
-            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0, res = 0.0;
-            if (want) { q0 = shc->pl[k][0]; q1 = shc->pl[k][1]; q2 = shc->pl[k][2]; q3 = shc->pl[k][3]; }
-            while (m) {
-                const int l = __ffsll((unsigned long long)m) - 1;
-                m &= m - 1ull;
-                const double nx = readlane_f64(q0, l), ny = readlane_f64(q1, l), nz = readlane_f64(q2, l), d0 = readlane_f64(q3, l);
-                // same order as vertex_error: lane-local sum over i = lane, lane + 64, ..., then the wave sum
-                double part = 0.0;
+    __shared__ uint32_t n_pairs[kErrVertsPerGroup], q_base;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
+    const int slot = (int)blockIdx.x * kErrVertsPerGroup + wave;       // one vertex per wave
+    uint32_t v = 0, np = 0;
+    if (slot < g.V) {
+        v = uni(g.vorder[slot]);                                       // vertices with many points first
+        uint16_t* list = x.plist + ((size_t)blockIdx.y * g.V + v) * (kErrChainsPerBlock * 4);
+        // lane l looks at chains c0 + 16 l .. + 15: all sixteen codes are fetched before any is used
+        const uint8_t* row = x.need + (size_t)v * n_chains;
+        uint32_t code[16];
+        uint32_t mine = 0;
 #pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const double d = (((nx * px[j]) + (ny * py[j])) + (nz * pz[j])) + d0;
-                    part += __builtin_fabs(d);
-                }
-                if (NF < kErrRegPts) {
-                    constexpr int J = NF < kErrRegPts ? NF : 0;
-                    const double d = (((nx * px[J]) + (ny * py[J])) + (nz * pz[J])) + d0;
-                    part += tail ? __builtin_fabs(d) : 0.0;
-                } else {
-                    for (uint32_t i = b + (uint32_t)(kErrRegPts * kWave + lane); i < e; i += kWave) {
-                        const float4 p = g.pts[i];
-                        const double d = (((nx * (double)p.x) + (ny * (double)p.y)) + (nz * (double)p.z)) + d0;
-                        part += __builtin_fabs(d);
-                    }
-                }
-                const double r = wave_sum_f64(part);
-                if (lane == l) res = r;
-            }
-            // the mean: one division per lane for its own chain instead of one per evaluation
-            if (want) x.err[(size_t)cc * 4 * g.V + (size_t)k * g.V + v] = res / dn;
+        for (int k = 0; k < 16; ++k) {
+            const int cc = c0 + 16 * lane + k;
+            code[k] = cc < c1 ? (uint32_t)row[cc] : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mine += (uint32_t)__popc(code[k]);
+        // exclusive prefix over the lanes
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off, kWave);
+            if (lane >= off) incl += t;
+        }
+        np = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+        uint32_t at = incl - mine;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            uint32_t cbits = code[k];
+            while (cbits) {
+                const uint32_t pl = (uint32_t)__ffs((int)cbits) - 1u;
+                cbits &= cbits - 1u;
+                list[at++] = (uint16_t)(((uint32_t)(16 * lane + k) << 2) | pl);
+            }
+        }
+    }
+    if (lane == 0) n_pairs[wave] = np;
+    __syncthreads();
+    uint32_t my_first = 0, total = 0;
+    for (int s = 0; s < kErrVertsPerGroup; ++s) {
+        if (s == wave) my_first = total;
+        total += (n_pairs[s] + kWave - 1) / kWave;
+    }
+    if (!total) return;
+    if (tid == 0) q_base = atomicAdd(x.counters, total);
+    __syncthreads();
+    const uint32_t items = (np + kWave - 1) / kWave;                   // at most 64: one per lane
+    if ((uint32_t)lane < items) x.queue[q_base + my_first + (uint32_t)lane] = make_uint2(v | ((uint32_t)blockIdx.y << 16), (uint32_t)lane | (np << 8));
+}
+
+template <int G>
+MC_D void err_item(const MvGraph& g, const MvExchange& x, int v, int c0, const uint16_t* list, uint32_t first, uint32_t np, int lane)
+{
+    const uint32_t b = uni(g.pt_ptr[v]), cnt = uni(g.pt_ptr[v + 1]) - b;
+    const int jl = lane & 15, kl = lane >> 4;
+    // B: component kl (nx ny nz d) of the plane of pair 16 gi + jl; pairs past the list evaluate a zero plane
+    double bp[G];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        const uint32_t idx = first + (uint32_t)(16 * gi + jl);
+        bp[gi] = 0.0;
+        if (idx < np) { const uint32_t pr = list[idx]; bp[gi] = x.sh[c0 + (int)(pr >> 2)].pl[pr & 3u][kl]; }
+    }
+    // A: component kl (x y z 1) of point 16 t + jl
+    const double* pa = g.ptsd + ((size_t)b + (size_t)jl) * 4 + kl;
+    const uint32_t nblk = (cnt + 15u) >> 4, tail = cnt & 15u;
+    const double4_t zero4 = { 0.0, 0.0, 0.0, 0.0 };
+    double ua[G], ub[G];                                     // the tree over q: (s0 + s1) in ub, then (s2 + s3) in ua
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) { ua[gi] = 0.0; ub[gi] = 0.0; }
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4u; ++q) {
+        double4_t acc[G];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) acc[gi] = zero4;
+        uint32_t t = q;
+        double a = t < nblk ? pa[(size_t)t * 64] : 0.0;
+        while (t < nblk) {
+            const uint32_t tn = t + 4u;
+            double an = 0.0;
+            if (tn < nblk) an = pa[(size_t)tn * 64];                  // the next block of this pass, under the products
+            double4_t d[G];
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) d[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[gi], zero4, 0, 0, 0);
+            if (tail != 0u && tn >= nblk && t == nblk - 1u) {        // the last block has rows past the vertex's points
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if ((uint32_t)(4 * r + kl) >= tail) d[gi][r] = 0.0;
+            }
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[gi][r] += __builtin_fabs(d[gi][r]);
+            a = an; t = tn;
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const double sq = (acc[gi][0] + acc[gi][1]) + (acc[gi][2] + acc[gi][3]);
+            if (q == 0u) ua[gi] = sq;
+            else if (q == 1u) ub[gi] = ua[gi] + sq;
+            else if (q == 2u) ua[gi] = sq;
+            else ua[gi] = ua[gi] + sq;
+        }
+    }
+    double res = 0.0;
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        double t = ub[gi] + ua[gi];
+        t = t + __shfl_xor(t, 16, kWave);
+        t = t + __shfl_xor(t, 32, kWave);
+        if (kl == gi) res = t;
+    }
+    // lane l writes pair l of the item: the mean, one division per pair
+    const uint32_t idx = first + (uint32_t)lane;
+    if (kl < G && idx < np) {
+        const uint32_t pr = list[idx];
+        x.err[(size_t)(c0 + (int)(pr >> 2)) * 4 * g.V + (size_t)(pr & 3u) * g.V + v] = res / (double)cnt;
     }
 }
 
-__global__ __launch_bounds__(kMvThreads) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
+__global__ __launch_bounds__(kWave) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
 {
-    const int lane = (int)threadIdx.x & 63;
-    const int v = uni((int)(blockIdx.x * kMvWaves + (threadIdx.x >> 6)));     // scalar, and so are its CSR bounds
-    if (v >= g.V) return;
-    const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
-    {   // nothing wanted from this vertex by these chains: leave before touching its points
-        bool any = false;
-        for (int cb = c0; cb < c1; cb += kWave) {
-            const int cc = cb + lane;
-            any = any || (cc < c1 && x.need[(size_t)v * n_chains + cc] != 0);
+    const int lane = (int)threadIdx.x;
+    const uint32_t n_items = uni(x.counters[0]);               // cleared by the second half of the iteration
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint2 rec = x.queue[item];
+        const int v = (int)uni(rec.x & 0xFFFFu);
+        const uint32_t by = uni(rec.x >> 16), it = uni(rec.y & 0xFFu), np = uni(rec.y >> 8);
+        const int c0 = (int)by * kErrChainsPerBlock;
+        const uint16_t* list = x.plist + ((size_t)by * g.V + v) * (kErrChainsPerBlock * 4);
+        const uint32_t first = it * kWave, here = min(np - first, (uint32_t)kWave);
+        switch ((here + 15u) >> 4) {
+            case 1: err_item<1>(g, x, v, c0, list, first, np, lane); break;
+            case 2: err_item<2>(g, x, v, c0, list, first, np, lane); break;
+            case 3: err_item<3>(g, x, v, c0, list, first, np, lane); break;
+            default: err_item<4>(g, x, v, c0, list, first, np, lane); break;
         }
-        if (!__ballot(any)) return;
-    }
-    const uint32_t b = uni(g.pt_ptr[v]), e = uni(g.pt_ptr[v + 1]);
-    const uint32_t cnt = e - b;
-    // the vertex's points, widened once: every (chain, plane) evaluation is then arithmetic only
-    double px[kErrRegPts], py[kErrRegPts], pz[kErrRegPts];
-#pragma unroll
-    for (int j = 0; j < kErrRegPts; ++j) {
-        const uint32_t i = (uint32_t)(j * kWave + lane);
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < cnt) p = g.pts[b + i];
-        px[j] = (double)p.x; py[j] = (double)p.y; pz[j] = (double)p.z;
-    }
-    switch (cnt / (uint32_t)kWave) {
-#define MV_ERR_CASE(N) case N: err_block<N>(g, n_chains, x, v, c0, c1, b, e, px, py, pz, lane); break
-        MV_ERR_CASE(0); MV_ERR_CASE(1); MV_ERR_CASE(2); MV_ERR_CASE(3); MV_ERR_CASE(4);
-        MV_ERR_CASE(5); MV_ERR_CASE(6); MV_ERR_CASE(7); MV_ERR_CASE(8); MV_ERR_CASE(9);
-#undef MV_ERR_CASE
-        default: err_block<kErrRegPts>(g, n_chains, x, v, c0, c1, b, e, px, py, pz, lane); break;
     }
 }
 
@@ -1032,23 +1126,29 @@ hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream
 
 size_t mv_exchange_shared_bytes() { return sizeof(MvShared); }
 
-// the same `steps` iterations as three kernels per iteration (see mv_chain_run_kernel)
-hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, void* ex_sh, uint8_t* ex_inE, uint8_t* ex_need,
-                                     double* ex_err, hipStream_t st)
+// the same `steps` iterations as four kernels per iteration (see mv_chain_run_kernel)
+size_t mv_split_plist_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * (kErrChainsPerBlock * 4); }
+size_t mv_split_queue_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * kErrItemsPerBlock; }
+
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, hipStream_t st)
 {
     if (g.V > kMvMaxV) return hipErrorInvalidValue;
     hipError_t e = mv_set_lds_attr();
     if (e != hipSuccess) return e;
     const size_t bytes = mv_lds_bytes(g.V, false);
     if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
-    MvExchange x{ reinterpret_cast<MvShared*>(ex_sh), ex_inE, ex_need, ex_err };
-    const dim3 egrid((unsigned)((g.V + kMvWaves - 1) / kMvWaves), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
-    if (egrid.y > 65535u) return hipErrorInvalidValue;      // > 4 M chains per launch: shard the chains
+    MvExchange x{ reinterpret_cast<MvShared*>(bufs.sh), bufs.inE, bufs.need, bufs.err, bufs.plist, bufs.queue, bufs.counters };
+    const dim3 pgrid((unsigned)((g.V + kErrVertsPerGroup - 1) / kErrVertsPerGroup), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
+    if (pgrid.y > 65535u) return hipErrorInvalidValue;      // > 64 M chains per launch: shard the chains
+    // error kernel: a fixed number of waves that share the queue; more than the items of a typical iteration would only idle
+    const size_t qmax = mv_split_queue_entries(g.V, a0.n_chains);
+    const unsigned ewaves = (unsigned)std::min<size_t>(qmax, 4096);
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
         hipLaunchKernelGGL(mv_chain_run_kernel<1>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
-        hipLaunchKernelGGL(mv_errors_kernel, egrid, dim3(kMvThreads), 0, st, g, a.n_chains, x);
+        hipLaunchKernelGGL(mv_err_pairs_kernel, pgrid, dim3(kErrVertsPerGroup * kWave), 0, st, g, a.n_chains, x);
+        hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), 0, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
     }
     return hipGetLastError();

@@ -6,6 +6,8 @@
 * over-segmentation parameters, IO::readSegmentationParams (IO.cpp:105-134): seven lines, value
   then "# name": windowSize, spatialStdev, disparityStdev, weightThreshold, colorFactor,
   disparityFactor, distanceFactor.
+* a Kinect frame as PNG pair (the reference bundles color{1,2,3}.png / depth{1,2,3}.png; its own PNG route,
+  SimpleSeg.cpp:88-101, is compiled out): load_frame_png.
 * most-visited labelling as an image, Problem::printResults (Problem.cpp:305-370): one flat colour per
   segment over the superpixels' pixels.
 """
@@ -35,6 +37,36 @@ def read_raw_data(path, width=640, height=480):
     c = data[:, 1].astype(np.uint64)
     colors = np.stack([(c & 0xFF), (c >> 8) & 0xFF, (c >> 16) & 0xFF], axis=1).astype(np.uint8).reshape(height, width, 3)
     return disp, colors
+
+
+# depth -> disparity of load_frame_png: the 1/8-pixel disparity units of the Kinect, d = round(8 f B / z)
+KINECT_FOCAL_PX = 580.0
+KINECT_BASELINE_M = 0.10
+DEPTH_PNG_UNITS_PER_M = 5000.0
+
+
+def depth_to_disparity(raw):
+    """16-bit depth image values (1/5000 m, 0 = no reading) -> int16 disparity in 1/8 pixel, 0 where there is no
+    reading.  The reference receives disparities from the sensor driver (SimpleSeg.cpp:137-192); for the bundled
+    PNG frames this conversion is the build's definition (tests/golden/make_c1_fixture.py uses it)."""
+    raw = np.asarray(raw).astype(np.int64)
+    z = raw / DEPTH_PNG_UNITS_PER_M
+    with np.errstate(divide="ignore"):
+        d = np.where(raw > 0, np.rint(8.0 * KINECT_FOCAL_PX * KINECT_BASELINE_M / z), 0.0)
+    if d.max(initial=0.0) > 32767:
+        raise ValueError("disparity does not fit int16")
+    return d.astype(np.int16)
+
+
+def load_frame_png(color_path, depth_path):
+    """(disp int16 (H, W), colors uint8 (H, W, 3) in cv::Vec3b order B, G, R) from an RGB8 colour PNG and a
+    16-bit depth PNG of the same size (what cv::imread would hand OverSegmentation::overSegment)."""
+    from PIL import Image           # data files only; nothing is executed
+    rgb = np.asarray(Image.open(color_path).convert("RGB"), np.uint8)
+    raw = np.asarray(Image.open(depth_path))
+    if raw.ndim != 2 or rgb.shape[:2] != raw.shape:
+        raise ValueError(f"colour {rgb.shape} and depth {raw.shape} images do not match")
+    return depth_to_disparity(raw), np.ascontiguousarray(rgb[:, :, ::-1])
 
 
 PARAM_NAMES = ("window_size", "spatial_stdev", "disparity_stdev", "weight_threshold", "color_factor",

@@ -1,7 +1,7 @@
 /*
  * multiview_oracle.c -- ORACLE.  TEST INFRASTRUCTURE ONLY.
  *
- * CPU restatement (plain C, f64, no FMA contraction) of Path B of a-price/MCMC,
+ * CPU restatement (plain C, f64, no FMA contraction; the one explicit fma chain is vertex_error's) of Path B of a-price/MCMC,
  * the "Price multiview" proposal evaluation:
  *
  *   B1  MathUtils::fitPlaneSVD            src/libraries/MathUtils.cpp:22-54
@@ -165,7 +165,27 @@ static void plane_from_moments(const double *m, double *plane)
     plane[4] = ((A[0][0] * A[1][1]) * A[2][2]) / 8.0;              /* det(U S^2 U^T / 2) */
 }
 
-/* B2: mean |n.p + d| over the vertex's points, wave order */
+/* B2: mean |n.p + d| over the vertex's points (SPGraph.cpp:89-104; the reference evaluates n.p + d in float and
+ * adds the |.| in a double, point after point).
+ * The residual of a point is the chain  fma(d, 1, fma(nz, z, fma(ny, y, fma(nx, x, 0)))) : products enter the sum
+ * unrounded, one rounding per term, in this order -- which is bit for bit what the f64 matrix instruction of the
+ * device (v_mfma_f64_16x16x4_f64, a row of 4 products added to C = 0) returns; measured with
+ * tools/micro/mfma_f64_probe.hip against exact rational arithmetic, 6144 of 6144 results.
+ * The |.| are added into 64 partial sums by point index mod 64 (ascending index), and the partials m = 16 q + 4 r + g
+ * are combined as a fixed tree: over r, then over q, then over g (the order in which the device holds them: r in
+ * the registers of a lane, q in passes, g across the rows of a wave). */
+static double vertex_tree_sum(const double *p /* 64 */)
+{
+    double u[4];
+    for (int g = 0; g < 4; ++g) {
+        double s[4];
+        for (int q = 0; q < 4; ++q)
+            s[q] = (p[16 * q + g] + p[16 * q + 4 + g]) + (p[16 * q + 8 + g] + p[16 * q + 12 + g]);
+        u[g] = (s[0] + s[1]) + (s[2] + s[3]);
+    }
+    return (u[0] + u[1]) + (u[2] + u[3]);
+}
+
 static double vertex_error(const float *pts, const uint32_t *pt_ptr, int v, const double *plane)
 {
     double part[NLANE];
@@ -173,10 +193,13 @@ static double vertex_error(const float *pts, const uint32_t *pt_ptr, int v, cons
     const uint32_t b = pt_ptr[v], e = pt_ptr[v + 1];
     for (uint32_t i = b; i < e; ++i) {
         double x = pts[4 * i], y = pts[4 * i + 1], z = pts[4 * i + 2];
-        double d = ((plane[0] * x + plane[1] * y) + plane[2] * z) + plane[3];
-        part[(i - b) & 63u] += d < 0.0 ? -d : d;
+        double d = fma(x, plane[0], 0.0);
+        d = fma(y, plane[1], d);
+        d = fma(z, plane[2], d);
+        d = fma(1.0, plane[3], d);
+        part[(i - b) & 63u] += fabs(d);
     }
-    return orc_wave_sum(part) / (double)(e - b);
+    return vertex_tree_sum(part) / (double)(e - b);
 }
 
 typedef struct {

@@ -224,10 +224,16 @@ def _oracle_pipeline(disp, col, w=9, sstd=5.0, dstd=3.0, c=300, cf=1.0, df=1.0, 
     return dict(smoothed=sm, a=a, b=b, w=wt, root=root, label=label, S=S, row_ptr=rp, col=cl)
 
 
-def test_config1_frame_through_the_oracle(c1):
-    # config 1: the reference's frame with output/overSegmentationParams.txt (9 / 5.0 / 3.0 / 300 / 1 / 1 / 1)
-    disp, col = c1
-    r = _oracle_pipeline(disp, col)
+@pytest.mark.parametrize("frame", [1, 2, 3])
+def test_bundled_frames_through_the_oracle(frame):
+    # config 1: the reference's frames with its own output/overSegmentationParams.txt (9 / 5.0 / 3.0 / 300 / 1 / 1 / 1)
+    from mcmc_amd import io
+    z = np.load(os.path.join(HERE, "golden", f"c{frame}_frame.npz"))
+    disp, col = np.ascontiguousarray(z["disp"]), np.ascontiguousarray(z["colors"])
+    prm = io.read_segmentation_params(os.path.join(HERE, "golden", "overSegmentationParams.txt"))
+    r = _oracle_pipeline(disp, col, w=prm["window_size"], sstd=prm["spatial_stdev"], dstd=prm["disparity_stdev"],
+                         c=prm["weight_threshold"], cf=prm["color_factor"], df=prm["disparity_factor"],
+                         distf=prm["distance_factor"])
     S = r["S"]
     assert 50 < S < 20000
     mom = O.moments(disp, r["label"], S)

@@ -1,4 +1,6 @@
 """On-disk formats: mcmc_amd/io.py against the formats of IO.cpp."""
+import os
+
 import numpy as np
 import pytest
 
@@ -32,6 +34,41 @@ def test_segmentation_params_file(tmp_path):
     p.write_text("9\t# windowSize \n5.0\t# spatialStdev \n")
     with pytest.raises(ValueError):
         io.read_segmentation_params(p)                    # "Missing line", IO.cpp:117
+
+
+def test_reference_params_file():
+    # the reference's own output/overSegmentationParams.txt (tests/golden/make_c1_fixture.py copies it byte for byte):
+    # tabs and spaces before '#', trailing blanks, the values of BASELINE config 1
+    d = io.read_segmentation_params(os.path.join(os.path.dirname(__file__), "golden", "overSegmentationParams.txt"))
+    assert d == dict(window_size=9, spatial_stdev=5.0, disparity_stdev=3.0, weight_threshold=300,
+                     color_factor=1.0, disparity_factor=1.0, distance_factor=1.0)
+
+
+def test_depth_to_disparity_and_png_loader(tmp_path):
+    from PIL import Image
+    # 1/5000 m units, d = round(8 * 580 * 0.10 / z): 1 m -> 464, 2 m -> 232, 0 stays 0, halves round to even (np.rint)
+    raw = np.array([[5000, 10000, 0], [4640, 2320, 65535]], np.uint16)
+    want = np.array([[464, 232, 0], [500, 1000, 35]], np.int16)
+    assert np.array_equal(io.depth_to_disparity(raw), want)
+    with pytest.raises(ValueError):
+        io.depth_to_disparity(np.array([[1]], np.uint16))          # 2 320 000 does not fit int16
+    rgb = np.arange(18, dtype=np.uint8).reshape(2, 3, 3)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    Image.fromarray(raw).save(tmp_path / "d.png")
+    disp, col = io.load_frame_png(tmp_path / "c.png", tmp_path / "d.png")
+    assert np.array_equal(disp, want) and np.array_equal(col, rgb[:, :, ::-1])      # cv::Vec3b is B, G, R
+    Image.fromarray(raw[:, :2]).save(tmp_path / "d2.png")
+    with pytest.raises(ValueError):
+        io.load_frame_png(tmp_path / "c.png", tmp_path / "d2.png")
+
+
+def test_bundled_frames_are_the_loader_output():
+    # the three bundled frames as fixtures: what load_frame_png made of color{1,2,3}.png / depth{1,2,3}.png
+    for k in (1, 2, 3):
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"c{k}_frame.npz"))
+        assert z["disp"].shape == (480, 640) and z["disp"].dtype == np.int16 and z["colors"].shape == (480, 640, 3)
+        d = z["disp"]
+        assert 0.10 < (d == 0).mean() < 0.16 and d[d > 0].min() >= 120 and d.max() < 600
 
 
 def test_segments_image():
