@@ -311,22 +311,37 @@ def multiview_line(host, device, n_chains, steps):
     # algorithmic bytes for K4 (2 passes x 16 B per point); the chains share the points through L2 / registers,
     # so this rate may exceed the HBM peak -- it is reported, not claimed as a roofline fraction
     alg = None
+    l1 = None
     if n_chains >= 32:
         m.set_option("profile", 1)
         m.chains_run(steps)
         m.synchronize() if hasattr(m, "synchronize") else None
-        pts = float(m.profile()[10]) / (n_chains * steps)
+        p = m.profile().astype(float)
+        pts = p[10] / (n_chains * steps)
         alg = {"points_per_proposal": pts, "bytes_per_proposal": 32.0 * pts,
                "GB_per_s": 32.0 * pts * n_chains * steps / (ms * 1e-3) / 1e9,
-               "evaluations_per_proposal": float(m.profile()[11]) / (n_chains * steps)}
+               "evaluations_per_proposal": p[11] / (n_chains * steps),
+               "point_residuals_per_proposal": p[12] / (n_chains * steps)}
+        # K4's bound is the f64 matrix pipe: a residual |n.p + d| is 4 FMAs of one v_mfma_f64_16x16x4_f64 lane-slot,
+        # 78.6 TFLOP/s dense f64 matrix peak (= 64 cycles per instruction and SIMD, tools/micro/mfma_f64_rate.hip).
+        # Algorithmic flops = 8 per residual asked for; the whole iteration (growth, plane fits, L1 pass, accept) is
+        # timed, so this is the fraction of the peak that the ITERATION reaches; the L1 kernel alone is in
+        # profiles/r02_multiview_kernel_stats.csv + r02_multiview_pmc.txt (MfmaUtil).
+        flops = 8.0 * p[12]
+        l1 = {"bound": "mfma", "dtype": "f64", "peak": 78.6, "unit": "TFLOP/s",
+              "achieved_whole_iteration": flops / (ms * 1e-3) / 1e12, "frac_whole_iteration": flops / (ms * 1e-3) / 78.6e12,
+              "matrix_instructions_per_iteration": 16.0 * p[21] / steps if p[19] else None,
+              "slots_per_residual": 16.0 * p[21] * 256.0 / p[12] if p[12] and p[19] else None,
+              "note": "matrix-instruction count from one timed item in 16 (diagnostic counters); per-kernel times and MfmaUtil of "
+                      "the L1 kernel are in profiles/ (rocprofv3), the first half of the iteration (component growth) is latency bound"}
     m.close()
     return {"workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
             "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,
             "accept_rate": float(sc["n_accept"].sum()) / (2.0 * n_chains * steps),
-            "algorithmic": alg,
-            "bound": "f64 VALU of the L1 residual pass (evaluated for all chains vertex by vertex, points read once per "
-                     "vertex block); the per-chain growth is breadth first over four waves"}
+            "algorithmic": alg, "l1_pass": l1,
+            "bound": "iteration = growth (latency: breadth first over four waves per chain, bitmap adjacency rows) + plane fits + "
+                     "L1 residual pass on the f64 matrix cores (one (chain, plane) pair per column, 16 points per instruction)"}
 
 
 def main():

@@ -312,8 +312,11 @@ int mcmc_mv_chains_get_planes(mcmc_mv *mv, int chain, double *out /* n_segments*
 /* Diagnostic (no counterpart in the reference): with option "profile" = 1 the first half of a split
  * iteration sums shader-clock cycles per phase over all chains of the last run: [0] set-up, [1] start vertex,
  * [2] growth, [3] move type / neighbour segments, [4] planes, [5] hand-over, [6] write-back, [8] growth levels,
- * [9] grown vertices, [10] points in SB1 u SB2, [11] (vertex, plane) residual evaluations requested. */
-int mcmc_mv_chains_get_profile(mcmc_mv *mv, uint64_t *out16);
+ * [9] grown vertices, [10] points in SB1 u SB2, [11] (vertex, plane) residual evaluations requested, [12] point
+ * residuals requested; and the L1 kernel, summed over one item in 16: [16] cycles before the first block (item record,
+ * pair list, planes), [17] cycles in the block loop, [18] cycles after it, [19] items, [20] blocks of 16 points,
+ * [21] matrix instructions, [22] waves that had an item, [23] their cycles from first to last item. */
+int mcmc_mv_chains_get_profile(mcmc_mv *mv, uint64_t *out32);
 double mcmc_mv_last_run_ms(mcmc_mv *mv);
 
 #ifdef __cplusplus

@@ -15,7 +15,9 @@ LIB = os.path.join(HERE, "libmcmc_amd.so")
 SOURCES = ["capi.hip", "capi_multiview.hip", "capi_overseg.hip", "frame_kernels.hip", "chain_kernels.hip", "multiview_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         # matrix-core results straight into VGPRs (no AGPR copies): the L1 pass of Path B reads every result once
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def sources():

@@ -32,7 +32,7 @@ struct mcmc_mv {
     uint8_t* trace = nullptr; double* trace_a = nullptr;
     // split step: exchange buffers between the two halves of an iteration and the error kernel
     void* ex_sh = nullptr; uint8_t *ex_inE = nullptr, *ex_need = nullptr; double* ex_err = nullptr;
-    uint16_t* ex_plist = nullptr; uint2* ex_queue = nullptr; uint32_t* ex_counters = nullptr;
+    uint16_t* ex_plist = nullptr; uint4* ex_queue = nullptr; uint32_t* ex_counters = nullptr;
     int opt_split = -1;   // -1 automatic (split from 32 chains on), 0 fused, 1 split
     int opt_prof = 0;
     unsigned long long* d_prof = nullptr;
@@ -420,8 +420,8 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         MVCHK(c, hipMemsetAsync(c->ex_counters, 0, 2 * sizeof(uint32_t), c->stream));
     }
     if (c->opt_prof) {
-        if (!c->d_prof) MVCHK(c, mvalloc(&c->d_prof, 16));
-        MVCHK(c, hipMemsetAsync(c->d_prof, 0, 16 * 8, c->stream));
+        if (!c->d_prof) MVCHK(c, mvalloc(&c->d_prof, 32));
+        MVCHK(c, hipMemsetAsync(c->d_prof, 0, 32 * 8, c->stream));
         a.prof = c->d_prof;
     }
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -436,11 +436,11 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     return MCMC_OK;
 }
 
-int mcmc_mv_chains_get_profile(mcmc_mv* c, uint64_t* out16)
+int mcmc_mv_chains_get_profile(mcmc_mv* c, uint64_t* out32)
 {
-    if (!c || !out16 || !c->d_prof) return mfail(c, MCMC_E_STATE, "mv_chains_get_profile: set option profile and run first");
+    if (!c || !out32 || !c->d_prof) return mfail(c, MCMC_E_STATE, "mv_chains_get_profile: set option profile and run first");
     MVCHK(c, hipSetDevice(c->device));
-    MVCHK(c, hipMemcpyAsync(out16, c->d_prof, 16 * 8, hipMemcpyDeviceToHost, c->stream));
+    MVCHK(c, hipMemcpyAsync(out32, c->d_prof, 32 * 8, hipMemcpyDeviceToHost, c->stream));
     MVCHK(c, hipStreamSynchronize(c->stream));
     return MCMC_OK;
 }

@@ -158,7 +158,7 @@ hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream
 // device buffers of the split iteration (capi_multiview.hip allocates them; sizes from the functions below)
 struct MvSplitBufs {
     void* sh; uint8_t* inE; uint8_t* need; double* err;     // [C] shared blocks, [C][V], [V][C], [C][4][V]
-    uint16_t* plist; uint2* queue; uint32_t* counters;      // mv_split_plist_entries, mv_split_queue_entries, [2] zeroed once
+    uint16_t* plist; uint4* queue; uint32_t* counters;      // mv_split_plist_entries, mv_split_queue_entries, [2] zeroed once
 };
 size_t mv_split_plist_entries(int V, int n_chains);
 size_t mv_split_queue_entries(int V, int n_chains);

@@ -17,6 +17,7 @@
 // the refits and the point pass use all 256 lanes.  All f64 results are produced
 // by IEEE operations in a fixed, documented order
 // (wave-order sums, det_exp / det_sqrt from + - * / only, fixed Jacobi sweeps).
+#include <cstdlib>
 #include "device_math.hpp"
 #include "kernels.hpp"
 
@@ -107,27 +108,29 @@ MC_D double point_residual(double nx, double ny, double nz, double d0, double x,
     d = __builtin_fma(z, nz, d);
     return __builtin_fma(1.0, d0, d);
 }
-// 64 partial sums m = 16 q + 4 r + g, one per lane, combined over r, then q, then g (see mv_errors_kernel: r sits in
-// the registers of a lane there, q in passes, g across the rows of the wave); every lane ends with the same bits
+// 16 partial sums m = 4 r + g (point index mod 16), one per lane of a row of 16 lanes, combined over r, then g (see
+// mv_errors_kernel: r sits in the registers of a lane there, g across the rows of the wave); every lane of the row
+// ends with the same bits
 MC_D double vertex_tree_sum(double v)
 {
     v = v + __shfl_xor(v, 4, kWave);
     v = v + __shfl_xor(v, 8, kWave);
-    v = v + __shfl_xor(v, 16, kWave);
-    v = v + __shfl_xor(v, 32, kWave);
     v = v + __shfl_xor(v, 1, kWave);
     v = v + __shfl_xor(v, 2, kWave);
     return v;
 }
+// one vertex, one wave: the first 16 lanes work (the partial sums are defined by point index mod 16), every lane returns the mean
 MC_D double vertex_error(const float4* pts, uint32_t b, uint32_t e, const double* pl, int lane)
 {
     const double nx = pl[0], ny = pl[1], nz = pl[2], d0 = pl[3];
     double part = 0.0;
-    for (uint32_t i = b + (uint32_t)lane; i < e; i += kWave) {
-        const float4 p = pts[i];
-        part += __builtin_fabs(point_residual(nx, ny, nz, d0, (double)p.x, (double)p.y, (double)p.z));
-    }
-    return vertex_tree_sum(part) / (double)(e - b);
+    if (lane < 16)
+        for (uint32_t i = b + (uint32_t)lane; i < e; i += 16u) {
+            const float4 p = pts[i];
+            part += __builtin_fabs(point_residual(nx, ny, nz, d0, (double)p.x, (double)p.y, (double)p.z));
+        }
+    const double t = vertex_tree_sum(part);
+    return readlane_f64(t, 0) / (double)(e - b);
 }
 
 __global__ __launch_bounds__(256) void mv_vertex_moments_kernel(MvGraph g, double* out)
@@ -394,7 +397,9 @@ struct MvExchange {
     uint8_t* need;      // [V][C] bit k: the L1 residual of vertex v under plane k of this chain is wanted
     double* err;        // [C][4][V]
     uint16_t* plist;    // [chain blocks][V][4096] the pairs (chain in block << 2 | plane) that want a vertex's residual
-    uint2* queue;       // [chain blocks * V * 64] items of 64 pairs: .x vertex | chain block << 16, .y item | pairs << 8
+    uint4* queue;       // [chain blocks * V * 64] items of 64 pairs: .x vertex | chain block << 16, .y item | pairs << 8,
+                        // .z first point of the vertex, .w its point count
+    unsigned long long* prof;   // option "profile": the L1 kernel's counters [16..23] (mcmc_mv_chains_get_profile), else null
     uint32_t* counters; // [0] queue length: counted up by mv_err_pairs_kernel, cleared by the second half
 };
 
@@ -782,14 +787,14 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
 // list and cuts it into items of up to 64 pairs; the items of a workgroup's 16 vertices go to a queue with one
 // atomic (vertices with many points come first, so the queue is roughly by descending cost).
 //
-// mv_errors_kernel: a wave takes items i, i + waves, ...  The residuals of 16 points under 16 planes are one
+// mv_errors_kernel: a wave takes an item.  The residuals of 16 points under 16 planes are one
 // v_mfma_f64_16x16x4_f64: A = the points (row = point, k = x y z 1), B = the planes (k = nx ny nz d, column = pair),
 // C = 0; the instruction adds the four products of a row as a chain of FMAs in k order, which is the definition of
 // the residual (point_residual above, and the oracle).  Lane l holds column l % 16 (a pair) and rows 4 r + l / 16
-// (points) in its four result registers r, so |.| is added with plain vector adds, lane by lane, into the partial
-// sums by point index mod 64: m = 16 q + 4 r + g with q = block mod 4 (one pass over the blocks per q), r the
-// register, g = l / 16.  The tree over r and q needs no data movement, the one over g is two cross-row exchanges
-// per group of 16 pairs and item.  Up to four groups of 16 pairs share the points of an item.
+// (points) in its four result registers r, so |.| is added with plain vector adds, lane by lane, into the 16 partial
+// sums by point index mod 16: m = 4 r + g with r the register and g = l / 16.  The tree over r needs no data
+// movement, the one over g is two cross-row exchanges per group of 16 pairs and item.  Up to four groups of 16
+// pairs share the points of an item.  Measured: 64 cycles per instruction and SIMD (tools/micro/mfma_f64_rate.hip).
 constexpr int kErrChainsPerBlock = 1024;
 constexpr int kErrItemsPerBlock = kErrChainsPerBlock * 4 / kWave;      // at most 64 items per (vertex, chain block)
 constexpr int kErrVertsPerGroup = 16;                                  // vertices per workgroup of mv_err_pairs_kernel
@@ -846,98 +851,106 @@ __global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel
     if (tid == 0) q_base = atomicAdd(x.counters, total);
     __syncthreads();
     const uint32_t items = (np + kWave - 1) / kWave;                   // at most 64: one per lane
-    if ((uint32_t)lane < items) x.queue[q_base + my_first + (uint32_t)lane] = make_uint2(v | ((uint32_t)blockIdx.y << 16), (uint32_t)lane | (np << 8));
+    if ((uint32_t)lane < items) {
+        const uint32_t b = g.pt_ptr[v];
+        x.queue[q_base + my_first + (uint32_t)lane] = make_uint4(v | ((uint32_t)blockIdx.y << 16), (uint32_t)lane | (np << 8), b, g.pt_ptr[v + 1] - b);
+    }
 }
 
 template <int G>
-MC_D void err_item(const MvGraph& g, const MvExchange& x, int v, int c0, const uint16_t* list, uint32_t first, uint32_t np, int lane)
+MC_D void err_item(const MvGraph& g, const MvExchange& x, const uint4 rec, int lane, unsigned long long t_item)
 {
-    const uint32_t b = uni(g.pt_ptr[v]), cnt = uni(g.pt_ptr[v + 1]) - b;
+    unsigned long long* const prof = t_item ? x.prof : nullptr;      // one item in 16 is timed (the counters are shared)
+    const int v = (int)(rec.x & 0xFFFFu), c0 = (int)(rec.x >> 16) * kErrChainsPerBlock;
+    const uint32_t first = (rec.y & 0xFFu) * kWave, np = rec.y >> 8, b = rec.z, cnt = rec.w;
+    const uint16_t* list = x.plist + ((size_t)(rec.x >> 16) * g.V + v) * (kErrChainsPerBlock * 4);
     const int jl = lane & 15, kl = lane >> 4;
     // B: component kl (nx ny nz d) of the plane of pair 16 gi + jl; pairs past the list evaluate a zero plane
+    uint32_t pr[G];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) { const uint32_t idx = first + (uint32_t)(16 * gi + jl); pr[gi] = idx < np ? (uint32_t)list[idx] : 0xFFFFFFFFu; }
+    const uint32_t widx = first + (uint32_t)lane;
+    const uint32_t wpr = (kl < G && widx < np) ? (uint32_t)list[widx] : 0xFFFFFFFFu;      // the pair this lane writes
     double bp[G];
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-        const uint32_t idx = first + (uint32_t)(16 * gi + jl);
-        bp[gi] = 0.0;
-        if (idx < np) { const uint32_t pr = list[idx]; bp[gi] = x.sh[c0 + (int)(pr >> 2)].pl[pr & 3u][kl]; }
-    }
-    // A: component kl (x y z 1) of point 16 t + jl
-    const double* pa = g.ptsd + ((size_t)b + (size_t)jl) * 4 + kl;
+    for (int gi = 0; gi < G; ++gi) bp[gi] = pr[gi] != 0xFFFFFFFFu ? x.sh[c0 + (int)(pr[gi] >> 2)].pl[pr[gi] & 3u][kl] : 0.0;
+    // A: component kl (x y z 1) of point 16 t + jl; four blocks are on their way while one is multiplied
+    const double* pbase = g.ptsd + (size_t)b * 4;             // uniform; the lane's part of the address is a 32-bit offset
+    const uint32_t loff = (uint32_t)(jl * 4 + kl);
     const uint32_t nblk = (cnt + 15u) >> 4, tail = cnt & 15u;
     const double4_t zero4 = { 0.0, 0.0, 0.0, 0.0 };
-    double ua[G], ub[G];                                     // the tree over q: (s0 + s1) in ub, then (s2 + s3) in ua
+    double4_t acc[G];
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) { ua[gi] = 0.0; ub[gi] = 0.0; }
-#pragma unroll 1
-    for (uint32_t q = 0; q < 4u; ++q) {
-        double4_t acc[G];
+    for (int gi = 0; gi < G; ++gi) acc[gi] = zero4;
+    double ring[4];
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi) acc[gi] = zero4;
-        uint32_t t = q;
-        double a = t < nblk ? pa[(size_t)t * 64] : 0.0;
-        while (t < nblk) {
-            const uint32_t tn = t + 4u;
-            double an = 0.0;
-            if (tn < nblk) an = pa[(size_t)tn * 64];                  // the next block of this pass, under the products
-            double4_t d[G];
+    for (int w = 0; w < 4; ++w) ring[w] = (uint32_t)w < nblk ? (pbase + (size_t)w * 64)[loff] : 0.0;
+    unsigned long long t_loop = 0ull;
+    if (prof) {      // the planes have arrived: everything before the first block
+        t_loop = __builtin_readcyclecounter() + (unsigned long long)(d2u(bp[0]) & 1ull) * 0ull;
+        if (lane == 0) atomicAdd(prof + 16, t_loop - t_item);
+    }
+    for (uint32_t t0 = 0u; t0 < nblk; t0 += 4u) {
 #pragma unroll
-            for (int gi = 0; gi < G; ++gi) d[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[gi], zero4, 0, 0, 0);
-            if (tail != 0u && tn >= nblk && t == nblk - 1u) {        // the last block has rows past the vertex's points
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t t = t0 + (uint32_t)w;
+            if (t >= nblk) break;
+            const double a = ring[w];
+            if (t + 4u < nblk) ring[w] = (pbase + (size_t)(t + 4u) * 64)[loff];
+            const bool cut = tail != 0u && t == nblk - 1u;            // the last block has rows past the vertex's points
 #pragma unroll
-                for (int gi = 0; gi < G; ++gi)
+            for (int gi = 0; gi < G; ++gi) {
+                double4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[gi], zero4, 0, 0, 0);
+                if (cut) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if ((uint32_t)(4 * r + kl) >= tail) d[gi][r] = 0.0;
+                    for (int r = 0; r < 4; ++r) if ((uint32_t)(4 * r + kl) >= tail) d[r] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[gi][r] += __builtin_fabs(d[r]);
             }
-#pragma unroll
-            for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[gi][r] += __builtin_fabs(d[gi][r]);
-            a = an; t = tn;
-        }
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-            const double sq = (acc[gi][0] + acc[gi][1]) + (acc[gi][2] + acc[gi][3]);
-            if (q == 0u) ua[gi] = sq;
-            else if (q == 1u) ub[gi] = ua[gi] + sq;
-            else if (q == 2u) ua[gi] = sq;
-            else ua[gi] = ua[gi] + sq;
         }
     }
+    unsigned long long t_end = 0ull;
+    if (prof) {
+        t_end = __builtin_readcyclecounter() + (unsigned long long)(d2u(acc[0][0]) & 1ull) * 0ull;
+        if (lane == 0) { atomicAdd(prof + 17, t_end - t_loop); atomicAdd(prof + 20, (unsigned long long)nblk); atomicAdd(prof + 21, (unsigned long long)nblk * G); }
+    }
+    // the tree: over r in the lane, over g across the four rows of the wave
     double res = 0.0;
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
-        double t = ub[gi] + ua[gi];
+        double t = (acc[gi][0] + acc[gi][1]) + (acc[gi][2] + acc[gi][3]);
         t = t + __shfl_xor(t, 16, kWave);
         t = t + __shfl_xor(t, 32, kWave);
         if (kl == gi) res = t;
     }
     // lane l writes pair l of the item: the mean, one division per pair
-    const uint32_t idx = first + (uint32_t)lane;
-    if (kl < G && idx < np) {
-        const uint32_t pr = list[idx];
-        x.err[(size_t)(c0 + (int)(pr >> 2)) * 4 * g.V + (size_t)(pr & 3u) * g.V + v] = res / (double)cnt;
-    }
+    if (wpr != 0xFFFFFFFFu) x.err[(size_t)(c0 + (int)(wpr >> 2)) * 4 * g.V + (size_t)(wpr & 3u) * g.V + v] = res / (double)cnt;
+    if (prof && lane == 0) { atomicAdd(prof + 18, __builtin_readcyclecounter() - t_end); atomicAdd(prof + 19, 1ull); }
 }
 
 __global__ __launch_bounds__(kWave) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
 {
     const int lane = (int)threadIdx.x;
     const uint32_t n_items = uni(x.counters[0]);               // cleared by the second half of the iteration
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint2 rec = x.queue[item];
-        const int v = (int)uni(rec.x & 0xFFFFu);
-        const uint32_t by = uni(rec.x >> 16), it = uni(rec.y & 0xFFu), np = uni(rec.y >> 8);
-        const int c0 = (int)by * kErrChainsPerBlock;
-        const uint16_t* list = x.plist + ((size_t)by * g.V + v) * (kErrChainsPerBlock * 4);
-        const uint32_t first = it * kWave, here = min(np - first, (uint32_t)kWave);
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch).  The items of a vertex are neighbours in the queue and read
+    // the same points, so runs of 8 items go to one XCD and meet in its L2: wave i of XCD k takes item 8 (8 (i / 8) + k) + i % 8.
+    const uint32_t xcd = blockIdx.x & 7u, wi = blockIdx.x >> 3;
+    const uint32_t slot = ((wi >> 3) * 8u + xcd) * 8u + (wi & 7u);
+    const unsigned long long t_wave = x.prof ? __builtin_readcyclecounter() : 0ull;
+    for (uint32_t item = slot; item < n_items; item += gridDim.x) {
+        const unsigned long long t_item = (x.prof && (item & 15u) == 0u) ? __builtin_readcyclecounter() : 0ull;
+        uint4 rec = x.queue[item];
+        rec.x = uni(rec.x); rec.y = uni(rec.y); rec.z = uni(rec.z); rec.w = uni(rec.w);
+        const uint32_t here = min((rec.y >> 8) - (rec.y & 0xFFu) * kWave, (uint32_t)kWave);
         switch ((here + 15u) >> 4) {
-            case 1: err_item<1>(g, x, v, c0, list, first, np, lane); break;
-            case 2: err_item<2>(g, x, v, c0, list, first, np, lane); break;
-            case 3: err_item<3>(g, x, v, c0, list, first, np, lane); break;
-            default: err_item<4>(g, x, v, c0, list, first, np, lane); break;
+            case 1: err_item<1>(g, x, rec, lane, t_item); break;
+            case 2: err_item<2>(g, x, rec, lane, t_item); break;
+            case 3: err_item<3>(g, x, rec, lane, t_item); break;
+            default: err_item<4>(g, x, rec, lane, t_item); break;
         }
     }
+    if (x.prof && lane == 0 && slot < n_items && (slot & 15u) == 0u) { atomicAdd(x.prof + 22, 1ull); atomicAdd(x.prof + 23, __builtin_readcyclecounter() - t_wave); }
 }
 
 // pMerge (GraphUtils.cpp:11-20): exp(-|w (.) |t2 - t1||^2 T / 2); one thread per pair
@@ -1137,12 +1150,13 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
     if (e != hipSuccess) return e;
     const size_t bytes = mv_lds_bytes(g.V, false);
     if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
-    MvExchange x{ reinterpret_cast<MvShared*>(bufs.sh), bufs.inE, bufs.need, bufs.err, bufs.plist, bufs.queue, bufs.counters };
+    MvExchange x{ reinterpret_cast<MvShared*>(bufs.sh), bufs.inE, bufs.need, bufs.err, bufs.plist, bufs.queue, a0.prof, bufs.counters };
     const dim3 pgrid((unsigned)((g.V + kErrVertsPerGroup - 1) / kErrVertsPerGroup), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
     if (pgrid.y > 65535u) return hipErrorInvalidValue;      // > 64 M chains per launch: shard the chains
     // error kernel: a fixed number of waves that share the queue; more than the items of a typical iteration would only idle
     const size_t qmax = mv_split_queue_entries(g.V, a0.n_chains);
-    const unsigned ewaves = (unsigned)std::min<size_t>(qmax, 4096);
+    unsigned ewaves = (unsigned)std::min<size_t>((qmax + 63) & ~(size_t)63, 16384);      // a multiple of 64: see the item mapping
+    if (const char* ev = std::getenv("MCMC_MV_EWAVES")) { const long n = std::atol(ev); if (n > 0) ewaves = (unsigned)(((size_t)n + 63) & ~(size_t)63); }   // tuning knob
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;

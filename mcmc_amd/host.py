@@ -473,7 +473,7 @@ class Multiview:
         return out
 
     def profile(self):
-        out = np.zeros(16, np.uint64)
+        out = np.zeros(32, np.uint64)
         self._ck(self.L.mcmc_mv_chains_get_profile(self.h, _ptr(out, np.uint64)))
         return out
 

@@ -171,24 +171,19 @@ static void plane_from_moments(const double *m, double *plane)
  * unrounded, one rounding per term, in this order -- which is bit for bit what the f64 matrix instruction of the
  * device (v_mfma_f64_16x16x4_f64, a row of 4 products added to C = 0) returns; measured with
  * tools/micro/mfma_f64_probe.hip against exact rational arithmetic, 6144 of 6144 results.
- * The |.| are added into 64 partial sums by point index mod 64 (ascending index), and the partials m = 16 q + 4 r + g
- * are combined as a fixed tree: over r, then over q, then over g (the order in which the device holds them: r in
- * the registers of a lane, q in passes, g across the rows of a wave). */
-static double vertex_tree_sum(const double *p /* 64 */)
+ * The |.| are added into 16 partial sums by point index mod 16 (ascending index), and the partials m = 4 r + g are
+ * combined as a fixed tree: over r, then over g (the way the device holds them: a 16 x 16 block of the matrix
+ * instruction puts rows 4 r + g of a column into register r of lane group g). */
+static double vertex_tree_sum(const double *p /* 16 */)
 {
-    double u[4];
-    for (int g = 0; g < 4; ++g) {
-        double s[4];
-        for (int q = 0; q < 4; ++q)
-            s[q] = (p[16 * q + g] + p[16 * q + 4 + g]) + (p[16 * q + 8 + g] + p[16 * q + 12 + g]);
-        u[g] = (s[0] + s[1]) + (s[2] + s[3]);
-    }
-    return (u[0] + u[1]) + (u[2] + u[3]);
+    double s[4];
+    for (int g = 0; g < 4; ++g) s[g] = (p[g] + p[4 + g]) + (p[8 + g] + p[12 + g]);
+    return (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 static double vertex_error(const float *pts, const uint32_t *pt_ptr, int v, const double *plane)
 {
-    double part[NLANE];
+    double part[16];
     memset(part, 0, sizeof part);
     const uint32_t b = pt_ptr[v], e = pt_ptr[v + 1];
     for (uint32_t i = b; i < e; ++i) {
@@ -197,7 +192,7 @@ static double vertex_error(const float *pts, const uint32_t *pt_ptr, int v, cons
         d = fma(y, plane[1], d);
         d = fma(z, plane[2], d);
         d = fma(1.0, plane[3], d);
-        part[(i - b) & 63u] += fabs(d);
+        part[(i - b) & 15u] += fabs(d);
     }
     return vertex_tree_sum(part) / (double)(e - b);
 }

@@ -23,3 +23,9 @@ if os.environ.get("PHASES"):
     for k, nm in enumerate(names):
         print(f"{nm:16s} {p[k] / n:10.0f} cycles per chain-step")
     print(f"levels {p[8] / n:.1f}  grown vertices {p[9] / n:.1f}")
+    st = float(os.environ.get("STEPS", 10))
+    if p[19]:
+        print(f"L1 kernel per iteration (one item in 16 is timed): items {16 * p[19] / st:.0f}  blocks {16 * p[20] / st:.0f}  matrix instructions {16 * p[21] / st:.0f}  "
+              f"residual slots / residuals asked {16 * p[21] * 256 / max(p[12], 1):.2f}")
+        print(f"  per item: before the loop {p[16] / p[19]:.0f} cycles, loop {p[17] / p[19]:.0f}, after {p[18] / p[19]:.0f}; "
+              f"waves with work {16 * p[22] / st:.0f}, cycles per such wave {p[23] / max(p[22], 1):.0f}")
