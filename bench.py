@@ -294,6 +294,24 @@ def c5_share_line(host, sc_list, device, frames=32, cpf=64, iters=1000, steps=2)
     return out
 
 
+def k3_bound_model(us_per_step):
+    """K3 has no byte stream: a chain step is ~2200 instructions per wave on LDS-resident tables, two waves per chain
+    (the second evaluates the next step speculatively), one chain per SIMD at C2 (1024 chains, 1024 SIMDs).  Its
+    bound is instruction issue of the SIMD: one wave-instruction per 4 cycles (tools/micro/valu_rate.hip: 2.9 - 6
+    cycles by opcode with four waves per SIMD).  Instruction counts are those of profiles/r02_k3_pmc.txt
+    (rocprofv3 --pmc, speculative kernel, launches of 2000 + 500 steps x 1024 chains); the step time is live."""
+    per_chain_step = (3390749429 + 1824715384 + 381802734 + 63038829) * 2 / (1024.0 * 2500.0)   # VALU + SALU + LDS + VMEM
+    model_us = per_chain_step * 4.0 / 2400.0
+    growth_lat = 14.96 * 4 * 65.8                  # passes x dependent LDS round trips x ds_read latency (r02_lds_latency.txt)
+    return {"kind": "instruction issue per SIMD: instructions per committed chain step x 4 cycles at 2.4 GHz, one chain per SIMD",
+            "instructions_per_chain_step": per_chain_step, "cycles_per_instruction": 4.0, "model_us_per_step": model_us,
+            "achieved_us_per_step": us_per_step, "frac": model_us / us_per_step,
+            "growth_dependent_lds_cycles_per_step": growth_lat,
+            "note": "both waves of a chain, wasted speculation included; the in-order critical path of the growth alone "
+                    "(passes x 4 dependent LDS round trips x 65.8 cycles) is what a single wave per chain could not hide; "
+                    "source of the counts: profiles/r02_k3_pmc.txt, r02_k3_phase_cycles.txt, r02_lds_latency.txt"}
+
+
 def multiview_line(host, device, n_chains, steps):
     """Path B (BASELINE configs[3], "C4"): 3 synthetic views, ~500 superpixels each, `n_chains` chains x `steps`
     proposals of the PatternedMatcher loop (the reference runs 20, PatternedMatcher.cpp:29)."""
@@ -491,7 +509,8 @@ def main():
         out["chain_kernel"] = {"kernel": "chain_run_kernel", "ms_per_launch": k3_ms,
                                "proposals_per_launch": n_local * a.iters_per_step,
                                "us_per_proposal_per_chain": k3_ms * 1e3 / a.iters_per_step,
-                               "bound": "latency (LDS-resident BFS); not an HBM claim"}
+                               "bound": "instruction issue (LDS-resident BFS, two waves per chain); not an HBM claim",
+                               "bound_model": k3_bound_model(k3_ms * 1e3 / a.iters_per_step)}
         out["frame_kernels_ms"] = {"sp_moments": ctx.last_kernel_ms(host.K_MOMENTS),
                                    "local_fit": ctx.last_kernel_ms(host.K_LOCAL_FIT),
                                    "edge_prob": ctx.last_kernel_ms(host.K_EDGE_PROB)}
