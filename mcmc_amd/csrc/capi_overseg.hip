@@ -8,12 +8,16 @@
 //
 // The filter and the edge weights are stencils over the frame (one 16x16 tile per workgroup, the tile
 // of disparities and colours in LDS, the disparity Gaussian from an LDS table because disparities are
-// integers); the union-find pass is a sequential scan over sorted edges and runs on the host, as in the
-// reference (std::sort on weight alone, so equal weights fall as this standard library leaves them,
-// which is what the reference's result depends on too); labels and the neighbour relation are built on
-// the device from the roots (rank of root pixels, S x S bit matrix, CSR by row).
+// integers).  The edges are sorted on the device (stable radix sort of the weight bits: equal weights stay in
+// creation order -- the reference sorts with std::sort on the weight alone, so there the order of equal weights
+// is whatever that standard library's introsort leaves; option "tie_order" = 1 runs that sort on the host
+// instead); the union-find pass is a sequential scan over the sorted edges and runs on the host, as in the
+// reference; labels and the neighbour relation are built on the device from the roots (rank of root pixels,
+// S x S bit matrix, CSR by row).
 // Restates behaviour, not code; every quirk kept is listed in DESIGN.md.
+#include <cstring>
 #include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -151,6 +155,22 @@ __global__ void edge_weight_kernel(const int16_t* disp, const uint8_t* smoothed,
     }
 }
 
+// Sort key of an edge slot: the weight's bits in an order-preserving form (sign flip for >= 0, complement for < 0),
+// all ones for a slot without an edge, so that those end up last; the value is the slot index (creation order).
+__global__ void edge_key_kernel(const int32_t* ea, const float* ew, uint32_t n, uint32_t* key, uint32_t* idx, int* n_valid)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = false;
+    if (s < n) {
+        valid = ea[s] >= 0;
+        const uint32_t bits = __float_as_uint(ew[s]);
+        key[s] = valid ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0xFFFFFFFFu;
+        idx[s] = s;
+    }
+    const uint64_t m = __ballot(valid);
+    if ((threadIdx.x & 63u) == 0u && m) atomicAdd(n_valid, (int)__popcll((unsigned long long)m));
+}
+
 // ---- labels from roots: rank of the root pixels in ascending pixel order ----
 // single workgroup, 1024 threads, contiguous chunks (N is a frame: a few 100k)
 __global__ __launch_bounds__(1024) void root_rank_kernel(const int32_t* root, int N, int32_t* rank, int* S_out)
@@ -235,7 +255,43 @@ struct Forest {
     }
 };
 
-int segment_graph_host(int nv, std::vector<WEdge>& edges, float c, std::vector<int32_t>& root)
+// The scan over edges that are already in order: slot s is the edge of pixel s / 4 in direction s % 4
+// (RIGHT, BOTTOM, BOTTOM-RIGHT, TOP-RIGHT), its weight comes back out of the sort key.  Same sets and same roots as
+// the reference's universe (union by rank, ties to the second root, disjoint-set.h:68-79): find() here halves the
+// path instead of re-linking only the queried element (:58-64), which changes how fast a root is reached, not which.
+struct FhNode { float thr; int32_t size, rank; };
+int segment_graph_sorted(int nv, int W, const uint32_t* slot, const uint32_t* key, size_t ne, float c, int32_t* root)
+{
+    std::vector<int32_t> p((size_t)nv);
+    std::vector<FhNode> nd((size_t)nv, FhNode{ c / 1, 1, 0 });
+    for (int i = 0; i < nv; ++i) p[(size_t)i] = i;
+    auto find = [&](int x) { while (p[(size_t)x] != x) { const int g = p[(size_t)p[(size_t)x]]; p[(size_t)x] = g; x = g; } return x; };
+    int sets = nv;
+    const int off[4] = { 1, W, W + 1, 1 - W };
+    for (size_t e = 0; e < ne; ++e) {
+        if (e + 16 < ne) __builtin_prefetch(&p[slot[e + 16] >> 2]);
+        const int a = (int)(slot[e] >> 2), b = a + off[slot[e] & 3u];
+        const int ra = find(a), rb = find(b);
+        if (ra == rb) continue;
+        const uint32_t kb = key[e];
+        const uint32_t bits = (kb & 0x80000000u) ? (kb & 0x7FFFFFFFu) : ~kb;
+        float w;
+        std::memcpy(&w, &bits, 4);
+        FhNode& na = nd[(size_t)ra];
+        FhNode& nb = nd[(size_t)rb];
+        if (w <= na.thr && w <= nb.thr) {
+            --sets;
+            int r;
+            if (na.rank > nb.rank) { p[(size_t)rb] = ra; na.size += nb.size; r = ra; }
+            else { p[(size_t)ra] = rb; nb.size += na.size; if (na.rank == nb.rank) nb.rank++; r = rb; }
+            nd[(size_t)r].thr = w + c / (float)(size_t)nd[(size_t)r].size;
+        }
+    }
+    for (int k = 0; k < nv; ++k) root[k] = find(k);
+    return sets;
+}
+
+int segment_graph_host(int nv, std::vector<WEdge>& edges, float c, int32_t* root)
 {
     std::sort(edges.begin(), edges.end(), [](const WEdge& x, const WEdge& y) { return x.w < y.w; });
     Forest f(nv);
@@ -251,8 +307,7 @@ int segment_graph_host(int nv, std::vector<WEdge>& edges, float c, std::vector<i
             thr[(size_t)r] = e.w + c / (float)(size_t)f.size[(size_t)r];
         }
     }
-    root.resize((size_t)nv);
-    for (int k = 0; k < nv; ++k) root[(size_t)k] = f.find(k);
+    for (int k = 0; k < nv; ++k) root[k] = f.find(k);
     return sets;
 }
 
@@ -270,13 +325,18 @@ struct mcmc_overseg {
     int* d_status = nullptr;          // [0] filter range flag, [1] S
     uint32_t *d_bits = nullptr, *d_deg = nullptr, *d_rowp = nullptr, *d_col = nullptr;
     size_t bits_cap = 0, col_cap = 0, row_cap = 0;
+    // the edge sort: keys and slot indices in and out, rocprim's scratch; the sorted lists and the roots cross the
+    // bus through pinned host memory
+    uint32_t *d_key = nullptr, *d_key2 = nullptr, *d_idx = nullptr, *d_idx2 = nullptr;
+    void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    uint32_t *p_key = nullptr, *p_idx = nullptr; int32_t* p_root = nullptr;
+    hipEvent_t ev[6] = {};
+    int opt_tie_order = 0;            // 0: equal weights in creation order (device sort); 1: std::sort on the host
     // results of the last run (host)
-    std::vector<int32_t> h_ea, h_eb, h_root;
-    std::vector<float> h_ew;
     std::vector<uint32_t> h_rowp, h_col;
     int S = 0; uint32_t e2 = 0;
     bool have = false;
-    float ms_filter = 0.f, ms_edges = 0.f, ms_fh = 0.f, ms_graph = 0.f;
+    float ms_filter = 0.f, ms_edges = 0.f, ms_fh = 0.f, ms_graph = 0.f, ms_sort = 0.f, ms_scan = 0.f;
 };
 
 namespace {
@@ -309,7 +369,17 @@ int mcmc_overseg_create(int device, int width, int height, mcmc_overseg** out)
          oalloc(&o->d_eb, N * 4) == hipSuccess && oalloc(&o->d_ew, N * 4) == hipSuccess &&
          oalloc(&o->d_root, N) == hipSuccess && oalloc(&o->d_rank, N) == hipSuccess && oalloc(&o->d_label, N) == hipSuccess &&
          oalloc(&o->d_sk, (size_t)kMaxWindow * kMaxWindow) == hipSuccess && oalloc(&o->d_gtab, 4096) == hipSuccess &&
-         oalloc(&o->d_status, 4) == hipSuccess;
+         oalloc(&o->d_status, 4) == hipSuccess &&
+         oalloc(&o->d_key, N * 4) == hipSuccess && oalloc(&o->d_key2, N * 4) == hipSuccess &&
+         oalloc(&o->d_idx, N * 4) == hipSuccess && oalloc(&o->d_idx2, N * 4) == hipSuccess;
+    if (ok) {
+        ok = rocprim::radix_sort_pairs(nullptr, o->sort_tmp_bytes, o->d_key, o->d_key2, o->d_idx, o->d_idx2, N * 4, 0, 32, o->stream) == hipSuccess &&
+             hipMalloc(&o->d_sort_tmp, std::max<size_t>(o->sort_tmp_bytes, 16)) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void**>(&o->p_key), N * 16, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void**>(&o->p_idx), N * 16, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void**>(&o->p_root), N * 4, hipHostMallocDefault) == hipSuccess;
+        for (int k = 0; ok && k < 6; ++k) ok = hipEventCreate(&o->ev[k]) == hipSuccess;
+    }
     if (!ok) { mcmc_overseg_destroy(o); return MCMC_E_DEVICE; }
     *out = o;
     return MCMC_OK;
@@ -323,6 +393,12 @@ int mcmc_overseg_destroy(mcmc_overseg* o)
     ofree(o->d_disp); ofree(o->d_colors); ofree(o->d_smoothed); ofree(o->d_ea); ofree(o->d_eb); ofree(o->d_ew);
     ofree(o->d_root); ofree(o->d_rank); ofree(o->d_label); ofree(o->d_sk); ofree(o->d_gtab); ofree(o->d_status);
     ofree(o->d_bits); ofree(o->d_deg); ofree(o->d_rowp); ofree(o->d_col);
+    ofree(o->d_key); ofree(o->d_key2); ofree(o->d_idx); ofree(o->d_idx2);
+    if (o->d_sort_tmp) (void)hipFree(o->d_sort_tmp);
+    if (o->p_key) (void)hipHostFree(o->p_key);
+    if (o->p_idx) (void)hipHostFree(o->p_idx);
+    if (o->p_root) (void)hipHostFree(o->p_root);
+    for (int k = 0; k < 6; ++k) if (o->ev[k]) (void)hipEventDestroy(o->ev[k]);
     if (o->stream) (void)hipStreamDestroy(o->stream);
     delete o;
     return MCMC_OK;
@@ -338,6 +414,13 @@ void mcmc_overseg_default_params(mcmc_overseg_params* p)
     p->color_factor = 1.0; p->disparity_factor = 1.0; p->distance_factor = 1.0;
 }
 
+int mcmc_overseg_set_option(mcmc_overseg* o, const char* name, int value)
+{
+    if (!o || !name) return ofail(o, MCMC_E_BADARG, "overseg_set_option: null argument");
+    if (std::string(name) == "tie_order" && (value == 0 || value == 1)) { o->opt_tie_order = value; return MCMC_OK; }
+    return ofail(o, MCMC_E_BADARG, std::string("overseg_set_option: unknown option or value: ") + name);
+}
+
 int mcmc_overseg_run(mcmc_overseg* o, const uint8_t* colors, const int16_t* disp, const mcmc_overseg_params* pp,
                      int* n_superpixels, uint32_t* n_directed_edges)
 {
@@ -351,9 +434,7 @@ int mcmc_overseg_run(mcmc_overseg* o, const uint8_t* colors, const int16_t* disp
     const int W = o->W, H = o->H, w = p.window_size;
     const size_t N = (size_t)W * H;
     o->have = false;
-    hipEvent_t e0, e1, e2, e3, e4;
-    OCHK(o, hipEventCreate(&e0)); OCHK(o, hipEventCreate(&e1)); OCHK(o, hipEventCreate(&e2));
-    OCHK(o, hipEventCreate(&e3)); OCHK(o, hipEventCreate(&e4));
+    hipEvent_t e0 = o->ev[0], e1 = o->ev[1], e2 = o->ev[2], e3 = o->ev[3], e4 = o->ev[4], e5 = o->ev[5];
     OCHK(o, hipMemcpyAsync(o->d_disp, disp, N * 2, hipMemcpyHostToDevice, o->stream));
     OCHK(o, hipMemcpyAsync(o->d_colors, colors, N * 3, hipMemcpyHostToDevice, o->stream));
     OCHK(o, hipMemsetAsync(o->d_status, 0, 4 * sizeof(int), o->stream));
@@ -394,26 +475,47 @@ int mcmc_overseg_run(mcmc_overseg* o, const uint8_t* colors, const int16_t* disp
                        p.color_factor, p.disparity_factor, p.distance_factor, o->d_ea, o->d_eb, o->d_ew);
     OCHK(o, hipGetLastError());
     OCHK(o, hipEventRecord(e2, o->stream));
-    std::vector<int32_t> ta(N * 4), tb(N * 4);
-    std::vector<float> tw(N * 4);
-    OCHK(o, hipMemcpyAsync(ta.data(), o->d_ea, N * 16, hipMemcpyDeviceToHost, o->stream));
-    OCHK(o, hipMemcpyAsync(tb.data(), o->d_eb, N * 16, hipMemcpyDeviceToHost, o->stream));
-    OCHK(o, hipMemcpyAsync(tw.data(), o->d_ew, N * 16, hipMemcpyDeviceToHost, o->stream));
     int st[4] = { 0, 0, 0, 0 };
-    OCHK(o, hipMemcpyAsync(st, o->d_status, sizeof st, hipMemcpyDeviceToHost, o->stream));
-    OCHK(o, hipStreamSynchronize(o->stream));
-    if (st[0]) return ofail(o, MCMC_E_RANGE, "overseg_run: filtered channel value outside 0..255");   // "Weird channel value."
-    // ---- 3. union-find on the host, edges in the reference's creation order
-    std::vector<WEdge> edges;
-    edges.reserve(N * 4);
-    o->h_ea.clear(); o->h_eb.clear(); o->h_ew.clear();
-    for (size_t s = 0; s < N * 4; ++s)
-        if (ta[s] >= 0) { edges.push_back(WEdge{ tw[s], ta[s], tb[s] }); o->h_ea.push_back(ta[s]); o->h_eb.push_back(tb[s]); o->h_ew.push_back(tw[s]); }
     const auto t0 = std::chrono::steady_clock::now();
-    segment_graph_host((int)N, edges, (float)(size_t)p.weight_threshold, o->h_root);
+    if (o->opt_tie_order == 0) {
+        // ---- 3. sort on the device (equal weights stay in creation order), union-find scan on the host
+        hipLaunchKernelGGL(edge_key_kernel, dim3((unsigned)((N * 4 + 255) / 256)), dim3(256), 0, o->stream, o->d_ea, o->d_ew,
+                           (uint32_t)(N * 4), o->d_key, o->d_idx, o->d_status + 2);
+        OCHK(o, hipGetLastError());
+        size_t tmp = o->sort_tmp_bytes;
+        OCHK(o, rocprim::radix_sort_pairs(o->d_sort_tmp, tmp, o->d_key, o->d_key2, o->d_idx, o->d_idx2, N * 4, 0, 32, o->stream));
+        OCHK(o, hipEventRecord(e5, o->stream));
+        OCHK(o, hipMemcpyAsync(st, o->d_status, sizeof st, hipMemcpyDeviceToHost, o->stream));
+        OCHK(o, hipMemcpyAsync(o->p_key, o->d_key2, N * 16, hipMemcpyDeviceToHost, o->stream));
+        OCHK(o, hipMemcpyAsync(o->p_idx, o->d_idx2, N * 16, hipMemcpyDeviceToHost, o->stream));
+        OCHK(o, hipStreamSynchronize(o->stream));
+        if (st[0]) return ofail(o, MCMC_E_RANGE, "overseg_run: filtered channel value outside 0..255");   // "Weird channel value."
+        (void)hipEventElapsedTime(&o->ms_sort, e2, e5);
+        const auto t1 = std::chrono::steady_clock::now();
+        segment_graph_sorted((int)N, W, o->p_idx, o->p_key, (size_t)st[2], (float)(size_t)p.weight_threshold, o->p_root);
+        o->ms_scan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    } else {
+        // ---- 3'. the reference's own order of equal weights: std::sort on the host over the edges in creation order
+        std::vector<int32_t> ta(N * 4), tb(N * 4);
+        std::vector<float> tw(N * 4);
+        OCHK(o, hipMemcpyAsync(ta.data(), o->d_ea, N * 16, hipMemcpyDeviceToHost, o->stream));
+        OCHK(o, hipMemcpyAsync(tb.data(), o->d_eb, N * 16, hipMemcpyDeviceToHost, o->stream));
+        OCHK(o, hipMemcpyAsync(tw.data(), o->d_ew, N * 16, hipMemcpyDeviceToHost, o->stream));
+        OCHK(o, hipMemcpyAsync(st, o->d_status, sizeof st, hipMemcpyDeviceToHost, o->stream));
+        OCHK(o, hipStreamSynchronize(o->stream));
+        if (st[0]) return ofail(o, MCMC_E_RANGE, "overseg_run: filtered channel value outside 0..255");   // "Weird channel value."
+        std::vector<WEdge> edges;
+        edges.reserve(N * 4);
+        for (size_t s = 0; s < N * 4; ++s)
+            if (ta[s] >= 0) edges.push_back(WEdge{ tw[s], ta[s], tb[s] });
+        const auto t1 = std::chrono::steady_clock::now();
+        segment_graph_host((int)N, edges, (float)(size_t)p.weight_threshold, o->p_root);
+        o->ms_scan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        o->ms_sort = 0.f;
+    }
     o->ms_fh = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     // ---- 4. labels and neighbours on the device
-    OCHK(o, hipMemcpyAsync(o->d_root, o->h_root.data(), N * 4, hipMemcpyHostToDevice, o->stream));
+    OCHK(o, hipMemcpyAsync(o->d_root, o->p_root, N * 4, hipMemcpyHostToDevice, o->stream));
     OCHK(o, hipEventRecord(e3, o->stream));
     hipLaunchKernelGGL(root_rank_kernel, dim3(1), dim3(1024), 0, o->stream, o->d_root, (int)N, o->d_rank, o->d_status + 1);
     OCHK(o, hipGetLastError());
@@ -448,7 +550,6 @@ int mcmc_overseg_run(mcmc_overseg* o, const uint8_t* colors, const int16_t* disp
     (void)hipEventElapsedTime(&o->ms_filter, e0, e1);
     (void)hipEventElapsedTime(&o->ms_edges, e1, e2);
     (void)hipEventElapsedTime(&o->ms_graph, e3, e4);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3); (void)hipEventDestroy(e4);
     o->S = S; o->e2 = E2; o->have = true;
     if (n_superpixels) *n_superpixels = S;
     if (n_directed_edges) *n_directed_edges = E2;
@@ -466,17 +567,29 @@ int mcmc_overseg_get_smoothed(mcmc_overseg* o, uint8_t* out)
 long long mcmc_overseg_get_edges(mcmc_overseg* o, int32_t* a, int32_t* b, float* w)
 {
     if (!o || !o->have) return ofail(o, MCMC_E_STATE, "overseg_get_edges: run first");
-    const size_t n = o->h_ea.size();
-    if (a) std::memcpy(a, o->h_ea.data(), n * 4);
-    if (b) std::memcpy(b, o->h_eb.data(), n * 4);
-    if (w) std::memcpy(w, o->h_ew.data(), n * 4);
+    // the slots stay on the device; packed to the reference's creation order only when somebody asks
+    const size_t N4 = (size_t)o->W * o->H * 4;
+    std::vector<int32_t> ta(N4), tb(N4);
+    std::vector<float> tw(N4);
+    if (hipSetDevice(o->device) != hipSuccess || hipMemcpy(ta.data(), o->d_ea, N4 * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(tb.data(), o->d_eb, N4 * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(tw.data(), o->d_ew, N4 * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return ofail(o, MCMC_E_DEVICE, "overseg_get_edges: copy failed");
+    size_t n = 0;
+    for (size_t s = 0; s < N4; ++s)
+        if (ta[s] >= 0) {
+            if (a) a[n] = ta[s];
+            if (b) b[n] = tb[s];
+            if (w) w[n] = tw[s];
+            ++n;
+        }
     return (long long)n;
 }
 
 int mcmc_overseg_get_roots(mcmc_overseg* o, int32_t* out)
 {
     if (!o || !out || !o->have) return ofail(o, MCMC_E_STATE, "overseg_get_roots: run first");
-    std::memcpy(out, o->h_root.data(), o->h_root.size() * 4);
+    std::memcpy(out, o->p_root, (size_t)o->W * o->H * 4);
     return MCMC_OK;
 }
 
@@ -511,6 +624,14 @@ int mcmc_overseg_last_ms(mcmc_overseg* o, float* filter_ms, float* edges_ms, flo
     if (edges_ms) *edges_ms = o->ms_edges;
     if (union_find_ms) *union_find_ms = o->ms_fh;
     if (graph_ms) *graph_ms = o->ms_graph;
+    return MCMC_OK;
+}
+
+int mcmc_overseg_last_sort_ms(mcmc_overseg* o, float* device_sort_ms, float* host_scan_ms)
+{
+    if (!o || !o->have) return ofail(o, MCMC_E_STATE, "overseg_last_sort_ms: run first");
+    if (device_sort_ms) *device_sort_ms = o->ms_sort;
+    if (host_scan_ms) *host_scan_ms = o->ms_scan;
     return MCMC_OK;
 }
 

@@ -133,6 +133,8 @@ def load():
         "mcmc_overseg_get_graph": (i, [vp, vp, vp]),
         "mcmc_overseg_device_buffers": (i, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "mcmc_overseg_last_ms": (i, [vp] + [C.POINTER(C.c_float)] * 4),
+        "mcmc_overseg_last_sort_ms": (i, [vp] + [C.POINTER(C.c_float)] * 2),
+        "mcmc_overseg_set_option": (i, [vp, C.c_char_p, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -563,4 +565,12 @@ class OverSegmenter:
     def last_ms(self):
         f = [C.c_float(0) for _ in range(4)]
         self._ck(self.L.mcmc_overseg_last_ms(self.h, *[C.byref(x) for x in f]))
-        return dict(zip(("filter", "edges", "union_find", "graph"), (x.value for x in f)))
+        g = [C.c_float(0) for _ in range(2)]
+        self._ck(self.L.mcmc_overseg_last_sort_ms(self.h, *[C.byref(x) for x in g]))
+        out = dict(zip(("filter", "edges", "union_find", "graph"), (x.value for x in f)))
+        out["device_sort"], out["host_scan"] = g[0].value, g[1].value
+        return out
+
+    def set_option(self, name, value):
+        """"tie_order": 0 = equal weights in creation order (device sort, default), 1 = std::sort on the host."""
+        self._ck(self.L.mcmc_overseg_set_option(self.h, name.encode(), int(value)))

@@ -8,9 +8,10 @@
 // literal Python transcription of the cited lines on inputs without weight ties
 // (tests/test_frontend.py) and by partition properties.
 //
-// Kept: edges sorted by weight alone with std::sort (segment-graph.h:35-37,53), so the order of
-// equal weights is whatever this standard library's introsort leaves -- the reference's result
-// depends on it too; merge iff w <= both thresholds (:92); threshold of a merged set =
+// Kept: edges sorted by weight alone (segment-graph.h:35-37,53).  The reference uses std::sort, so the
+// order of equal weights is whatever that standard library's introsort leaves -- the reference's result
+// depends on it.  tie_order 1 does the same call with this standard library; tie_order 0 (the product's
+// default) is the canonical order "equal weights in creation order" (std::stable_sort).  Merge iff w <= both thresholds (:92); threshold of a merged set =
 // w + c / size in float (:102, THRESHOLD at :27); find() compresses only the queried node's
 // link (disjoint-set.h:58-64); union by rank, ties go to the second root (:68-79).
 #include <algorithm>
@@ -34,11 +35,12 @@ struct Forest {
 // root_out[k] = find(k) after the pass, for every vertex in ascending k (the order in which
 // createSuperPixels queries the universe, OverSegmentation.cpp:110).  Returns the number of sets.
 extern "C" int orc_segment_graph(int nv, long long ne, const int32_t* ea, const int32_t* eb, const float* ew, float c,
-                                 int32_t* root_out)
+                                 int tie_order, int32_t* root_out)
 {
     std::vector<WEdge> edges((size_t)ne);
     for (long long i = 0; i < ne; ++i) { edges[i].w = ew[i]; edges[i].a = ea[i]; edges[i].b = eb[i]; }
-    std::sort(edges.begin(), edges.end(), [](const WEdge& x, const WEdge& y) { return x.w < y.w; });
+    if (tie_order == 1) std::sort(edges.begin(), edges.end(), [](const WEdge& x, const WEdge& y) { return x.w < y.w; });
+    else std::stable_sort(edges.begin(), edges.end(), [](const WEdge& x, const WEdge& y) { return x.w < y.w; });
     Forest f(nv);
     std::vector<float> thr((size_t)nv, c / 1);
     int sets = nv;

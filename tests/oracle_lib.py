@@ -86,7 +86,7 @@ def lib():
     L.orc_bilateral.argtypes = [i16p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p]
     L.orc_create_edges.restype = C.c_longlong
     L.orc_create_edges.argtypes = [i16p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, i32p, i32p, f32p]
-    L.orc_segment_graph.argtypes = [C.c_int, C.c_longlong, i32p, i32p, f32p, C.c_float, i32p]
+    L.orc_segment_graph.argtypes = [C.c_int, C.c_longlong, i32p, i32p, f32p, C.c_float, C.c_int, i32p]
     L.orc_superpixels.argtypes = [i32p, C.c_int, C.c_int, u16p, C.POINTER(C.c_int), u32p, u32p, C.c_longlong,
                                   C.POINTER(C.c_uint32)]
     _lib = L
@@ -275,10 +275,11 @@ def create_edges(disp, smoothed, color_factor=1.0, disparity_factor=1.0, distanc
     return a[:n].copy(), b[:n].copy(), w[:n].copy()
 
 
-def segment_graph(nv, a, b, w, c):
+def segment_graph(nv, a, b, w, c, tie_order=0):
+    """tie_order 0: equal weights in creation order (the product's default); 1: this C++ runtime's std::sort."""
     root = np.zeros(nv, np.int32)
     sets = lib().orc_segment_graph(nv, a.size, np.ascontiguousarray(a, np.int32), np.ascontiguousarray(b, np.int32),
-                                   np.ascontiguousarray(w, np.float32), float(c), root)
+                                   np.ascontiguousarray(w, np.float32), float(c), int(tie_order), root)
     return sets, root
 
 
