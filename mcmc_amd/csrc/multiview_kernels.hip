@@ -28,6 +28,10 @@ namespace mc {
 constexpr uint32_t kPhiloxTagMv = 0x4D564D43u;  // "MVMC"
 constexpr int kMvWaves = 4;
 constexpr int kMvThreads = kMvWaves * 64;
+constexpr int kMvWavesFirstHalf = 4;            // waves per chain in the first half of a split iteration (4 or 8).  Measured at C4: eight waves halve a chain's
+                                                // growth time when it has a CU to itself (88 k against 207 k cycles), but with four chains on a CU
+                                                // the iteration takes as long as with four waves (2.25 against 2.15 ms per 10 steps): the CU's
+                                                // throughput, not the chain's latency, is the limit
 constexpr int kMvMaxV = 64 * 64;                // a bitmap row is one 64-bit word per lane (the fused kernel's LDS allows ~3.4 k vertices)
 
 struct Sym33 { double a00, a01, a02, a11, a12, a22; };
@@ -268,7 +272,7 @@ struct MvLds {
     uint16_t *cur, *own, *elist, *sv;
     uint8_t *inE, *nb;
     uint32_t* se;       // [V] claim words of the growth (0 = free)
-    uint32_t* cand;     // [4][256] words: candidate edges per wave (init: 128 entry indices; run: 128 (entry, neighbour) pairs)
+    uint32_t* cand;     // [8][256] words: candidate edges per wave (init: 128 entry indices; run: 128 (entry, neighbour) pairs)
     double* errv;       // [4][V]
     MvShared* sh;
 };
@@ -278,7 +282,7 @@ struct MvLds {
 __host__ __device__ inline size_t mv_lds_bytes(int V, bool with_err)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return A(sizeof(MvShared)) + 4096 + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
+    return A(sizeof(MvShared)) + 8192 + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
 }
 
 MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
@@ -287,7 +291,7 @@ MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
     MvLds L;
     size_t o = 0;
     L.sh = reinterpret_cast<MvShared*>(smem + o); o += A(sizeof(MvShared));
-    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += 4096;
+    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += 8192;
     L.errv = reinterpret_cast<double*>(smem + o); if (with_err) o += A((size_t)V * 32);
     L.se = reinterpret_cast<uint32_t*>(smem + o); o += A((size_t)V * 4);
     L.cur = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
@@ -408,9 +412,13 @@ struct MvExchange {
 // MODE 1 / MODE 2: the first / second half of ONE iteration; between them mv_errors_kernel evaluates the
 // L1 residuals of all chains vertex by vertex, so a vertex's points are read once for every chain that
 // needs them instead of once per chain.  Same arithmetic in the same order, hence the same bits.
-template <int MODE>
-__global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
+// NW: waves per chain (kMvWavesFirstHalf for the first half of a split iteration); the segment fits use waves 0..3
+// whatever NW is.
+template <int MODE, int NW = kMvWaves>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 8 : 1, NW == 8 ? 8 : 10)))   // eight waves: 64 VGPRs, so that four chains share a CU
+void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
 {
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = g.V;
     MvLds L = mv_carve(smem, V, MODE == 0);
@@ -428,14 +436,14 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
     unsigned long long* EB = reinterpret_cast<unsigned long long*>(L.se);
     unsigned long long* NBU = EB + W64;
     unsigned long long* SM = reinterpret_cast<unsigned long long*>(L.sv);   // start's segment as a bitmap, per step
-    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
-    for (int w = tid; w < 2 * W64; w += kMvThreads) EB[w] = 0ull;
+    for (int v = tid; v < V; v += NT) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
+    for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
     if (MODE == 2) {
         // second half: the grown set, the shared block and the residuals come from the first half and the error kernel
-        for (int v = tid; v < V; v += kMvThreads) L.inE[v] = x.inE[(size_t)chain * V + v];
+        for (int v = tid; v < V; v += NT) L.inE[v] = x.inE[(size_t)chain * V + v];
         const uint32_t* src = reinterpret_cast<const uint32_t*>(x.sh + chain);
         uint32_t* dst = reinterpret_cast<uint32_t*>(sh);
-        for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += kMvThreads) dst[k] = src[k];
+        for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
         L.errv = x.err + (size_t)chain * 4 * V;
         if (chain == 0 && tid == 0) x.counters[0] = 0u;     // the error kernel has drained the queue: empty for the next iteration
     }
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         const unsigned long long t = a.step0 + ts;
         if (status != 0) {
             if (MODE != 2 && tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
-            if (MODE == 1) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
+            if (MODE == 1) for (int v = tid; v < V; v += NT) x.need[(size_t)v * a.n_chains + chain] = 0;
             continue;
         }
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             // as start" (S) and looks at word w of a frontier vertex's row, so one trip of a wave covers all 64 x 64
             // possible neighbours: candidates = row & S & ~set.  The words of the rows also pile up in U, from
             // which getNeighborSegments is answered after the growth.
-            for (int bw = wave; bw < W64; bw += kMvWaves) {
+            for (int bw = wave; bw < W64; bw += NW) {
                 const int j = bw * 64 + lane;
                 const unsigned long long m = __ballot(j < V && L.cur[j < V ? j : 0] == cs);
                 if (lane == 0) SM[bw] = m;
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 };
                 if (vi < tail) fetch(vi, aw, wb);
                 while (vi < tail) {
-                    const uint32_t vn = vi + (uint32_t)kMvWaves;
+                    const uint32_t vn = vi + (uint32_t)NW;
                     if (vn < tail) fetch(vn, naw, nwb);
                     U |= aw;
                     unsigned long long c = aw & S;
@@ -569,10 +577,10 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         if (kind == 3) {
             if (MODE == 2) break;                  // frozen and traced by the first half
             status = -6;
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
-            for (int w = tid; w < 2 * W64; w += kMvThreads) EB[w] = 0ull;
+            for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
+            for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
             if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
-            if (MODE == 1) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
+            if (MODE == 1) for (int v = tid; v < V; v += NT) x.need[(size_t)v * a.n_chains + chain] = 0;
             __syncthreads();
             continue;
         }
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         } else if (kind == 1) {
             // addNewSegment (MultiviewSegmentation.cpp:85-110): the vertices really move
             const uint32_t tg = sh->target;
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) {
+            for (uint32_t i = (uint32_t)tid; i < nE; i += NT) {
                 const uint32_t v = L.elist[i];
                 pvalid[L.own[v]] = 0;
                 L.own[v] = (uint16_t)tg;
@@ -662,11 +670,11 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                     const int n = pool_moments(g.vm, V, lane, [&](int v) { return member(2, v); }, m);
                     if (n > 0) plane_from_moments(m, p5);
                     else for (int k = 0; k < 5; ++k) p5[k] = planes[(size_t)orig * 5 + k];   // fit skipped (:37)
-                } else {
+                } else if (wave == 3) {
                     pool_moments(g.vm, V, lane, [&](int v) { return member(3, v); }, m);
                     plane_from_moments(m, p5);
                 }
-                if (lane == 0) {
+                if (lane == 0 && wave < 4) {
                     for (int k = 0; k < 5; ++k) sh->pl[wave][k] = p5[k];
                     sh->have[wave] = cached;
                     if (cached) sh->P[wave] = segP[wave == 0 ? orig : target];
@@ -678,7 +686,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             const int h0 = sh->have[0], h1 = sh->have[1];
             if (MODE == 1) {
                 int prof_pts = 0, prof_ev = 0, prof_pe = 0;
-                for (int v = tid; v < V; v += kMvThreads) {
+                for (int v = tid; v < V; v += NT) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
                     const uint32_t nb4 = (uint32_t)(!h0 && o == orig) | ((uint32_t)(!h1 && o == target) << 1) |
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
                 }
             }
             if (MODE == 0)
-            for (int v = wave; v < V; v += kMvWaves) {
+            for (int v = wave; v < V; v += NW) {
                 const uint32_t o = L.own[v];
                 const bool ie = L.inE[v] != 0;
                 const bool m0 = !h0 && o == orig, m1 = !h1 && o == target;
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
             }
             __syncthreads();
             // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
-            if (MODE != 1 && !sh->have[wave]) {
+            if (MODE != 1 && wave < 4 && !sh->have[wave]) {
                 // four rows per trip, fetched whether or not they are members (in the split iteration the table is
                 // behind L2 and a fetch per member would be one round trip after the other); only members are
                 // added, in vertex order
@@ -742,11 +750,11 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         }
         if (MODE == 1) {
             // first half done: hand the shared block over (a skipped proposal wants no residuals)
-            if (kind == 2) for (int v = tid; v < V; v += kMvThreads) x.need[(size_t)v * a.n_chains + chain] = 0;
+            if (kind == 2) for (int v = tid; v < V; v += NT) x.need[(size_t)v * a.n_chains + chain] = 0;
             __syncthreads();
             const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
             uint32_t* dst = reinterpret_cast<uint32_t*>(x.sh + chain);
-            for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += kMvThreads) dst[k] = src[k];
+            for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
             stamp(5);
             continue;
         }
@@ -767,13 +775,13 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_run_kernel(MvGraph g, MvC
         }
         // clear the step's flags (the halves of a split step start from cleared LDS instead)
         if (MODE == 0) {
-            for (uint32_t i = (uint32_t)tid; i < nE; i += kMvThreads) L.inE[L.elist[i]] = 0;
-            for (int w = tid; w < 2 * W64; w += kMvThreads) EB[w] = 0ull;
-            for (int v = tid; v < V; v += kMvThreads) L.nb[v] = 0;
+            for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
+            for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
+            for (int v = tid; v < V; v += NT) L.nb[v] = 0;
         }
         __syncthreads();
     }
-    if (MODE != 2) for (int v = tid; v < V; v += kMvThreads) gown[v] = L.own[v];
+    if (MODE != 2) for (int v = tid; v < V; v += NT) gown[v] = L.own[v];
     stamp(6);
     if (tid == 0) {
         if (MODE != 2) { a.nseg[chain] = nseg; a.status[chain] = status; a.n_split[chain] = n_split; }
@@ -1089,7 +1097,7 @@ static hipError_t mv_set_lds_attr()
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<1>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<1, kMvWavesFirstHalf>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<2>),
@@ -1160,7 +1168,7 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
-        hipLaunchKernelGGL(mv_chain_run_kernel<1>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+        hipLaunchKernelGGL((mv_chain_run_kernel<1, kMvWavesFirstHalf>), dim3(a.n_chains), dim3(kMvWavesFirstHalf * 64), bytes, st, g, a, x);
         hipLaunchKernelGGL(mv_err_pairs_kernel, pgrid, dim3(kErrVertsPerGroup * kWave), 0, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), 0, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
