@@ -14,6 +14,23 @@ for _ in range(3):
     S, e2 = o.run(col, disp)
 wall = (time.perf_counter() - t0) / 3 * 1e3
 print("C1: %d superpixels, %d directed edges; stage ms %s; wall %.1f ms per frame" % (S, e2, o.last_ms(), wall))
+# frames are independent: one handle (own stream, own pinned buffers) per host thread; the C call releases the GIL
+import threading
+nthr = int(os.environ.get("THREADS", 8)); per = 4
+hs = [host.OverSegmenter(640, 480) for _ in range(nthr)]
+for h in hs:
+    h.run(col, disp)
+def work(h):
+    for _ in range(per):
+        h.run(col, disp)
+t0 = time.perf_counter()
+th = [threading.Thread(target=work, args=(h,)) for h in hs]
+[t.start() for t in th]; [t.join() for t in th]
+wall_mt = time.perf_counter() - t0
+print("%d host threads, one handle each: %d frames in %.1f ms -> %.2f ms per frame, %.0f frames/s"
+      % (nthr, nthr * per, wall_mt * 1e3, wall_mt * 1e3 / (nthr * per), nthr * per / wall_mt))
+for h in hs:
+    h.close()
 ctx = host.Context(width=640, height=480)
 ctx.frames_alloc(1, S, e2)
 d_disp, d_label = o.device_buffers()
