@@ -268,11 +268,14 @@ MC_D double mv_unit(uint32_t x) { return (double)x / 4294967295.0; }
 // lanes of one wave exchanging data through LDS: stops the compiler from forwarding or reordering across it
 MC_D void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
+// candidate buffers: 1 KB per wave.  Kept at four waves' worth unless the first half really runs eight: with 8 KB the
+// per-chain state at C4 is 39 KB and only three chains fit a CU (first half 194 us instead of 132 us)
+constexpr size_t kMvCandBytes = (kMvWavesFirstHalf > kMvWaves ? kMvWavesFirstHalf : kMvWaves) * 1024;
 struct MvLds {
     uint16_t *cur, *own, *elist, *sv;
     uint8_t *inE, *nb;
     uint32_t* se;       // [V] claim words of the growth (0 = free)
-    uint32_t* cand;     // [8][256] words: candidate edges per wave (init: 128 entry indices; run: 128 (entry, neighbour) pairs)
+    uint32_t* cand;     // [waves][256] words: candidate edges per wave (init: 128 entry indices; run: 128 (entry, neighbour) pairs)
     double* errv;       // [4][V]
     MvShared* sh;
 };
@@ -282,7 +285,7 @@ struct MvLds {
 __host__ __device__ inline size_t mv_lds_bytes(int V, bool with_err)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return A(sizeof(MvShared)) + 8192 + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
+    return A(sizeof(MvShared)) + kMvCandBytes + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
 }
 
 MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
@@ -291,7 +294,7 @@ MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
     MvLds L;
     size_t o = 0;
     L.sh = reinterpret_cast<MvShared*>(smem + o); o += A(sizeof(MvShared));
-    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += 8192;
+    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += kMvCandBytes;
     L.errv = reinterpret_cast<double*>(smem + o); if (with_err) o += A((size_t)V * 32);
     L.se = reinterpret_cast<uint32_t*>(smem + o); o += A((size_t)V * 4);
     L.cur = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
@@ -415,7 +418,7 @@ struct MvExchange {
 // NW: waves per chain (kMvWavesFirstHalf for the first half of a split iteration); the segment fits use waves 0..3
 // whatever NW is.
 template <int MODE, int NW = kMvWaves>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 8 : 1, NW == 8 ? 8 : 10)))   // eight waves: 64 VGPRs, so that four chains share a CU
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 8 : 4)))   // four chains (of four or eight waves) per CU
 void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
 {
     constexpr int NT = NW * 64;

@@ -15,6 +15,9 @@ if os.environ.get("PHASES"):
     m.set_option("profile", 1)
 m.chains_run(int(os.environ.get("STEPS", 10)))
 print("ms per launch", m.last_run_ms())
+for _ in range(int(os.environ.get("REPEAT", 0))):
+    m.chains_run(int(os.environ.get("STEPS", 10)))
+    print("ms per launch (again)", m.last_run_ms())
 print("segments per chain (mean)", float(m.scalars()["n_segments"].mean()))
 if os.environ.get("PHASES"):
     p = m.profile().astype(float)
