@@ -254,6 +254,34 @@ def test_gpu_edge_trial_thresholds(gpu_mv, mv_small):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_chains", [37, 1030])
+def test_gpu_matrix_l1_pass_shapes(gpu_mv, n_chains):
+    """The L1 pass on the matrix cores at its edges: vertices of 1 to ~40 points (fewer than one block of 16, ragged
+    last blocks), chain counts that are no multiple of 16 / 64 and that span more than one block of 1024 chains
+    (second chain block of the pair lists and the queue), items with 1..4 groups of 16 pairs.  Split iteration
+    = oracle, bit for bit, for every chain."""
+    mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
+    cnt = np.diff(mv.pt_ptr.astype(np.int64))
+    assert cnt.min() < 16 and (cnt % 16 != 0).any() and cnt.max() > 16
+    _load(gpu_mv, mv)
+    gpu_mv.vertex_moments()
+    gpu_mv.set_option("split_step", 1)
+    steps = 6
+    gpu_mv.chains_init(n_chains, seed=3, max_new_segments=8, split_prob=0.2)
+    gpu_mv.chains_set_trace(steps)
+    gpu_mv.chains_run(steps)
+    gf, ga = gpu_mv.trace()
+    gs = gpu_mv.scalars()
+    gpu_mv.set_option("split_step", -1)
+    orc = O.MvChains(mv, n_chains, seed=3, max_new_segments=8, split_prob=0.2)
+    of, oa = orc.run(steps)
+    assert np.array_equal(gf, of) and np.array_equal(ga.view(np.uint64), oa.view(np.uint64))
+    s = orc.scalars()
+    for k in ("n_accept", "n_split", "n_skip", "trace_hash", "n_segments", "status"):
+        assert np.array_equal(gs[k], s[k]), k
+
+
+@pytest.mark.gpu
 def test_gpu_chains_capacity_overflow(gpu_mv, mv_small):
     _load(gpu_mv, mv_small)
     gpu_mv.chains_init(2, seed=1, max_new_segments=1, split_prob=1.0)
