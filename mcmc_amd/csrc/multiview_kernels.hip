@@ -315,28 +315,34 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
     const int chain = (int)blockIdx.x;
     // wave index as a scalar: the loops over "this wave's" vertices then get scalar control flow
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    for (int v = tid; v < V; v += kMvThreads) { L.cur[v] = 0xFFFFu; L.se[v] = 0u; }
+    // the claim words' space holds the bitmap of the vertices that have a component (as in the chain step)
+    const int W64 = g.W64;
+    unsigned long long* LB = reinterpret_cast<unsigned long long*>(L.se);
+    for (int v = tid; v < V; v += kMvThreads) L.cur[v] = 0xFFFFu;
+    for (int w = tid; w < W64; w += kMvThreads) LB[w] = 0ull;
     __syncthreads();
     {
         // Bernoulli(q) per undirected edge (draw index = rank of the edge, so both directions agree and the
         // order of the search does not matter), then connected components numbered by their smallest vertex.
         // A component is grown breadth first by the four waves, as in the chain step: a wave takes frontier
-        // vertices in turn, collects the out-edges to unlabelled vertices and tries them 64 at a time; a
-        // vertex is claimed with atomicExch on its claim word.
+        // vertices in turn; lane w looks at word w of the vertex's bitmap row (MvGraph::abm), candidates =
+        // row & ~(vertices that have a component); they are collected and tried 64 at a time (draw <= threshold);
+        // a vertex is claimed with an atomic OR on the bitmap.
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, 0xFFFFFFFFu, 0xFFFFFFFFu };
-        uint32_t* cb = L.cand + wave * 256;
+        uint2* cb = reinterpret_cast<uint2*>(L.cand + wave * 256);
         int ncomp = 0;
         for (int s0 = 0; s0 < V; ++s0) {
             if (L.cur[s0] != 0xFFFFu) continue;      // uniform over the workgroup (LDS value, read after a barrier)
             __syncthreads();                          // every wave has read cur[s0] before it is written
-            if (tid == 0) { L.cur[s0] = (uint16_t)ncomp; L.se[s0] = 1u; L.elist[0] = (uint16_t)s0; L.sh->nE = 1u; }
+            if (tid == 0) { L.cur[s0] = (uint16_t)ncomp; LB[s0 >> 6] |= 1ull << (s0 & 63); L.elist[0] = (uint16_t)s0; L.sh->nE = 1u; }
             __syncthreads();
-            auto try_edges = [&](uint32_t e, bool valid) {
+            auto try_edges = [&](uint2 ej, bool valid) {
                 if (!valid) return;
-                const uint32_t j = g.col[e];
-                if (L.cur[j] != 0xFFFFu) return;
-                const uint2 t = g.et[e];
-                if (mv_draw_at(rg, t.x) <= t.y && atomicExch(&L.se[j], 1u) == 0u) {   // u <= q, inclusive (:23), as draw <= threshold
+                const uint2 t = g.et[ej.x];
+                const uint32_t j = ej.y;
+                const unsigned long long bit = 1ull << (j & 63u);
+                if (LB[j >> 6] & bit) return;
+                if (mv_draw_at(rg, t.x) <= t.y && (atomicOr(&LB[j >> 6], bit) & bit) == 0ull) {   // u <= q, inclusive (:23), as draw <= threshold
                     const uint32_t idx = atomicAdd(&L.sh->nE, 1u);
                     L.elist[idx] = (uint16_t)j; L.cur[j] = (uint16_t)ncomp;
                 }
@@ -344,29 +350,41 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
             uint32_t head = 0, tail = 1;
             while (head < tail) {
                 uint32_t cn = 0;
-                for (uint32_t vi = head + (uint32_t)wave; vi < tail; vi += kMvWaves) {
-                    const uint32_t v = uni((uint32_t)L.elist[vi]);
-                    const uint32_t e1 = uni(g.rowp[v + 1]);
-                    for (uint32_t e0 = uni(g.rowp[v]); e0 < e1; e0 += kWave) {
-                        const uint32_t e = e0 + (uint32_t)lane;
-                        uint32_t j = 0;
-                        bool cand = false;
-                        if (e < e1) { j = g.col[e]; cand = L.cur[j] == 0xFFFFu; }
-                        const uint64_t m = __ballot(cand);
-                        if (m == 0) continue;
-                        if (cand) cb[cn + (uint32_t)mbcnt(m)] = e;
+                uint32_t vi = head + (uint32_t)wave;
+                unsigned long long aw = 0ull, naw = 0ull;
+                uint32_t wb = 0u, nwb = 0u;
+                auto fetch = [&](uint32_t at, unsigned long long& ra, uint32_t& rb) {
+                    const size_t r = (size_t)uni((uint32_t)L.elist[at]) * (size_t)W64;
+                    ra = 0ull; rb = 0u;
+                    if (lane < W64) { ra = g.abm[r + lane]; rb = g.wbase[r + lane]; }
+                };
+                if (vi < tail) fetch(vi, aw, wb);
+                while (vi < tail) {
+                    const uint32_t vn = vi + (uint32_t)kMvWaves;
+                    if (vn < tail) fetch(vn, naw, nwb);
+                    unsigned long long c = aw;
+                    if (c) c &= ~LB[lane];
+                    for (;;) {
+                        const uint64_t m = __ballot(c != 0ull);
+                        if (m == 0) break;
+                        if (c) {
+                            const int b = __ffsll((unsigned long long)c) - 1;
+                            cb[cn + (uint32_t)mbcnt(m)] = make_uint2(wb + (uint32_t)__popcll(aw & ((1ull << b) - 1ull)), (uint32_t)(lane * 64 + b));
+                            c &= c - 1ull;
+                        }
                         cn += (uint32_t)__popcll((unsigned long long)m);
                         wave_lds_fence();
                         if (cn >= (uint32_t)kWave) {
                             try_edges(cb[lane], true);
                             const uint32_t rest = cn - (uint32_t)kWave;
-                            const uint32_t keep = (uint32_t)lane < rest ? cb[kWave + lane] : 0u;
+                            const uint2 keep = (uint32_t)lane < rest ? cb[kWave + lane] : make_uint2(0u, 0u);
                             wave_lds_fence();
                             if ((uint32_t)lane < rest) cb[lane] = keep;
                             cn = rest;
                             wave_lds_fence();
                         }
                     }
+                    vi = vn; aw = naw; wb = nwb;
                 }
                 if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
                 __syncthreads();
@@ -1128,6 +1146,7 @@ hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* o
 
 hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st)
 {
+    if (g.V > kMvMaxV) return hipErrorInvalidValue;
     hipError_t e = mv_set_lds_attr();
     if (e != hipSuccess) return e;
     const size_t bytes = mv_lds_bytes(g.V, false);
