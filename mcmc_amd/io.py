@@ -8,8 +8,9 @@
   disparityFactor, distanceFactor.
 * a Kinect frame as PNG pair (the reference bundles color{1,2,3}.png / depth{1,2,3}.png; its own PNG route,
   SimpleSeg.cpp:88-101, is compiled out): load_frame_png.
-* most-visited labelling as an image, Problem::printResults (Problem.cpp:305-370): one flat colour per
-  segment over the superpixels' pixels.
+* a segmentation as an image, Problem::visualize (Problem.cpp:305-370): white background, one colour per segment
+  over its superpixels' pixels (or the angle between the superpixel's and the segment's plane normals), a component
+  in black, superpixel boundaries in black: visualize().  segments_image() is the plain palette image.
 """
 from __future__ import annotations
 
@@ -118,4 +119,78 @@ def segments_image(label_map, segment_of_superpixel, seed=0):
     s = np.where(lm < seg.size, seg[np.minimum(lm, seg.size - 1)], 0xFFFF)
     img = palette[np.minimum(s, palette.shape[0] - 1)]
     img[s == 0xFFFF] = 0
+    return img
+
+
+KINECT_FOCAL = 580.0        # kFocalLength, MyMath.h:30
+KINECT_BASELINE = 0.10      # kBaseline, MyMath.h:29
+
+
+def disparity_to_explicit(theta):
+    """MyMath.h:94-103: (a, b, c) of disparity = a u + b v + c (raw pixel coordinates) -> unit normal and distance
+    (nx, ny, nz, d).  theta: (..., 3)."""
+    theta = np.asarray(theta, np.float64)
+    a, b, c = theta[..., 0], theta[..., 1], theta[..., 2]
+    f = KINECT_FOCAL
+    n = np.sqrt(a * a + b * b + (c / f) * (c / f))
+    return np.stack([a / n, b / n, c / (f * n), KINECT_BASELINE / n], axis=-1)
+
+
+def raw_theta(theta_centred, width, height):
+    """The library fits planes in coordinates centred at (W/2, H/2); the reference's are raw
+    pixel coordinates: same a, b, and c_raw = c - a W/2 - b H/2."""
+    t = np.array(theta_centred, np.float64, copy=True)
+    t[..., 2] -= t[..., 0] * (width // 2) + t[..., 1] * (height // 2)
+    return t
+
+
+def boundary_pixels(label_map):
+    """createSuperPixels' boundaryPixels_ (OverSegmentation.cpp:174-190): a pixel whose superpixel differs from that of
+    its LEFT, TOP or TOP-RIGHT neighbour (the TOP-LEFT compare never registers: the ring buffer slot it reads has just
+    been overwritten with the pixel's own id, :174).  Bool (H, W)."""
+    lm = np.asarray(label_map)
+    out = np.zeros(lm.shape, bool)
+    out[:, 1:] |= lm[:, 1:] != lm[:, :-1]
+    out[1:, :] |= lm[1:, :] != lm[:-1, :]
+    out[1:, :-1] |= lm[1:, :-1] != lm[:-1, 1:]
+    return out
+
+
+def visualize(label_map, segment_of_superpixel, theta_superpixel=None, theta_segment=None, component=None,
+              draw_error=False, seed=0):
+    """Problem::visualize (Problem.cpp:305-370) as an (H, W, 3) uint8 image in cv::Vec3b order (B, G, R).
+
+    label_map (H, W) uint16 superpixel ids; segment_of_superpixel [S] segment id per superpixel, 0xFFFF = not
+    assigned (dropped by the A1 filter: stays white, as superpixels outside assignments_ do).  Without draw_error
+    every segment gets one colour (the reference draws rand() % 256 three times per segment, :343; here a seeded
+    generator).  With draw_error the colour is (e, e, 255), e = (size_t)(255 (1 - angle / (pi / 2))), angle between
+    the normals of disparityToExplicit(segment plane) and disparityToExplicit(superpixel plane), :323-334 -- thetas in
+    raw pixel coordinates (raw_theta), theta_segment indexed by segment id.  Superpixels of `component` are drawn
+    black ((125, 0, 125) with draw_error, :347-350); boundary pixels are black (:361-367)."""
+    lm = np.asarray(label_map).astype(np.int64)
+    seg = np.asarray(segment_of_superpixel).astype(np.int64)
+    S = seg.size
+    assigned = seg != 0xFFFF
+    if draw_error:
+        ns = disparity_to_explicit(np.asarray(theta_superpixel, np.float64))[:, :3]
+        ng = disparity_to_explicit(np.asarray(theta_segment, np.float64))[np.where(assigned, seg, 0), :3]
+        with np.errstate(invalid="ignore"):
+            angle = np.arccos(np.sum(ns * ng, axis=1))
+        e = 255.0 * (1.0 - angle / (np.pi / 2.0))
+        e = np.where(np.isfinite(e), e, 0.0)
+        e = np.clip(np.trunc(e), 0, 255).astype(np.uint8)          # (size_t) cast, then cv::saturate_cast<uchar>
+        col = np.stack([e, e, np.full(S, 255, np.uint8)], axis=1)
+    else:
+        rng = np.random.default_rng(seed)
+        palette = rng.integers(0, 256, (int(seg[assigned].max(initial=0)) + 1, 3)).astype(np.uint8)
+        col = palette[np.where(assigned, seg, 0)]
+    if component is not None:
+        col = col.copy()
+        col[np.asarray(component, np.int64)] = (125, 0, 125) if draw_error else (0, 0, 0)
+    img = np.full(lm.shape + (3,), 255, np.uint8)
+    inside = lm < S
+    sp = np.where(inside, lm, 0)
+    paint = inside & assigned[sp]
+    img[paint] = col[sp[paint]]
+    img[boundary_pixels(label_map)] = 0
     return img

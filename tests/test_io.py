@@ -76,3 +76,32 @@ def test_segments_image():
     img = io.segments_image(lm, np.array([5, 5, 0xFFFF], np.uint16))
     assert img.shape == (2, 3, 3)
     assert (img[0, 0] == img[0, 2]).all() and (img[1, 0] == 0).all() and (img[1, 2] == 0).all()
+
+
+def test_visualize_matches_the_reference_rendering():
+    # Problem::visualize (Problem.cpp:305-370): white where nothing is assigned, one colour per segment, component in
+    # black, boundary pixels (LEFT / TOP / TOP-RIGHT differ) in black
+    lm = np.array([[0, 0, 1, 1],
+                   [0, 0, 1, 1],
+                   [2, 2, 2, 3]], np.uint16)
+    seg = np.array([7, 7, 0xFFFF, 4], np.uint16)
+    b = io.boundary_pixels(lm)
+    want_b = np.array([[0, 0, 1, 0],
+                       [0, 1, 1, 0],          # (1,1): its TOP-RIGHT neighbour (0,2) is superpixel 1
+                       [1, 1, 1, 1]], bool)
+    assert np.array_equal(b, want_b)
+    img = io.visualize(lm, seg, seed=3)
+    assert (img[0, 0] == img[0, 3]).all() and not (img[0, 0] == 255).all()      # superpixels 0 and 1 share segment 7
+    assert (img[b] == 0).all()
+    img2 = io.visualize(lm, seg, component=[1], seed=3)
+    assert (img2[0, 3] == 0).all() and (img2[0, 0] == img[0, 0]).all()
+    # superpixel 2 is not assigned: white wherever it is not boundary (none here: the whole row is boundary)
+    lm2 = np.zeros((4, 4), np.uint16); lm2[2:] = 1
+    assert (io.visualize(lm2, np.array([0xFFFF, 0], np.uint16))[0] == 255).all()
+    # error colouring: identical planes -> angle 0 -> (255, 255, 255); orthogonal normals -> e = 0
+    th = np.array([[0.1, 0.2, 300.0], [0.1, 0.2, 300.0]])
+    e = io.visualize(lm2, np.array([0, 0], np.uint16), theta_superpixel=th, theta_segment=th[:1], draw_error=True)
+    assert e[0, 0, 2] == 255 and e[0, 0, 0] == e[0, 0, 1] and e[0, 0, 0] >= 254      # acos of a dot product within an ulp of 1, truncated
+    n = io.disparity_to_explicit(np.array([0.0, 0.0, 580.0]))
+    assert np.allclose(n, [0.0, 0.0, 1.0, 0.1])                                   # MyMath.h:94-103 with f = 580, B = 0.10
+    assert np.allclose(io.raw_theta(np.array([1.0, 2.0, 10.0]), 640, 480), [1.0, 2.0, 10.0 - 320.0 - 960.0])
