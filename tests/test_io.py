@@ -104,4 +104,4 @@ def test_visualize_matches_the_reference_rendering():
     assert e[0, 0, 2] == 255 and e[0, 0, 0] == e[0, 0, 1] and e[0, 0, 0] >= 254      # acos of a dot product within an ulp of 1, truncated
     n = io.disparity_to_explicit(np.array([0.0, 0.0, 580.0]))
     assert np.allclose(n, [0.0, 0.0, 1.0, 0.1])                                   # MyMath.h:94-103 with f = 580, B = 0.10
-    assert np.allclose(io.raw_theta(np.array([1.0, 2.0, 10.0]), 640, 480), [1.0, 2.0, 10.0 - 320.0 - 960.0])
+    assert np.allclose(io.raw_theta(np.array([1.0, 2.0, 10.0]), 640, 480), [1.0, 2.0, 10.0 - 320.0 - 480.0])
