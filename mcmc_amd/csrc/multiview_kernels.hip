@@ -729,18 +729,37 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                     }
                 }
             }
-            if (MODE == 0)
-            for (int v = wave; v < V; v += NW) {
-                const uint32_t o = L.own[v];
-                const bool ie = L.inE[v] != 0;
-                const bool m0 = !h0 && o == orig, m1 = !h1 && o == target;
-                const bool m2 = o == orig && !ie, m3 = o == target || ie;
-                if (!(m0 || m1 || m2 || m3)) continue;
-                const uint32_t b = g.pt_ptr[v], e = g.pt_ptr[v + 1];
-                if (m0) { const double x = vertex_error(g.pts, b, e, sh->pl[0], lane); if (lane == 0) L.errv[v] = x; }
-                if (m1) { const double x = vertex_error(g.pts, b, e, sh->pl[1], lane); if (lane == 0) L.errv[V + v] = x; }
-                if (m2) { const double x = vertex_error(g.pts, b, e, sh->pl[2], lane); if (lane == 0) L.errv[2 * V + v] = x; }
-                if (m3) { const double x = vertex_error(g.pts, b, e, sh->pl[3], lane); if (lane == 0) L.errv[3 * V + v] = x; }
+            if (MODE == 0) {
+                // A vertex's 16 partial sums (point index mod 16) live in one row of 16 lanes, so a wave takes four
+                // vertices at a time, one per row; plane k is evaluated for the rows that want it, the tree runs inside
+                // a row (its exchanges are xor 4, 8, 1, 2).
+                const int vrow = lane >> 4, m16 = lane & 15;
+                for (int vb = wave * 4; vb < V; vb += NW * 4) {
+                    const int v = vb + vrow;
+                    uint32_t nb4 = 0u, b = 0u, e = 0u;
+                    if (v < V) {
+                        const uint32_t o = L.own[v];
+                        const bool ie = L.inE[v] != 0;
+                        nb4 = (uint32_t)(!h0 && o == orig) | ((uint32_t)(!h1 && o == target) << 1) |
+                              ((uint32_t)(o == orig && !ie) << 2) | ((uint32_t)(o == target || ie) << 3);
+                        if (nb4) { b = g.pt_ptr[v]; e = g.pt_ptr[v + 1]; }
+                    }
+                    if (!__ballot(nb4 != 0u)) continue;
+#pragma unroll 1
+                    for (int k = 0; k < 4; ++k) {
+                        const bool want = ((nb4 >> k) & 1u) != 0u;
+                        if (!__ballot(want)) continue;
+                        const double nx = sh->pl[k][0], ny = sh->pl[k][1], nz = sh->pl[k][2], d0 = sh->pl[k][3];
+                        double part = 0.0;
+                        if (want)
+                            for (uint32_t i = b + (uint32_t)m16; i < e; i += 16u) {
+                                const float4 p = g.pts[i];
+                                part += __builtin_fabs(point_residual(nx, ny, nz, d0, (double)p.x, (double)p.y, (double)p.z));
+                            }
+                        const double t = vertex_tree_sum(part);
+                        if (want && m16 == 0) L.errv[(size_t)k * V + v] = t / (double)(e - b);
+                    }
+                }
             }
             __syncthreads();
             // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
