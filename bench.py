@@ -352,8 +352,19 @@ def multiview_line(host, device, n_chains, steps):
               "slots_per_residual": 16.0 * p[21] * 256.0 / p[12] if p[12] and p[19] else None,
               "note": "matrix-instruction count from one timed item in 16 (diagnostic counters); per-kernel times and MfmaUtil of "
                       "the L1 kernel are in profiles/ (rocprofv3), the first half of the iteration (component growth) is latency bound"}
+    # the same graph with four times the chains: 1024 chains are one round of four chains per CU and leave the
+    # iteration at twice a single chain's latency; more chains in flight raise the rate
+    more = None
+    if n_chains == 1024:
+        m.set_option("profile", 0)
+        m.chains_init(4096, seed=4, max_new_segments=4 * steps)
+        m.chains_run(steps)
+        m.chains_run(steps)
+        ms4 = m.last_run_ms()
+        more = {"chains": 4096, "proposals_per_s": 4096 * steps / (ms4 * 1e-3), "ms_per_launch": ms4}
     m.close()
-    return {"workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
+    return {"more_chains": more,
+            "workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
             "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,
             "accept_rate": float(sc["n_accept"].sum()) / (2.0 * n_chains * steps),
