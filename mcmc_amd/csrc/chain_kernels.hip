@@ -41,7 +41,34 @@ struct Rng {
     uint32_t k0, k1, step_lo, step_hi;
     int batch;
     double* buf;                  // LDS, [4][64]: the batch's draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
+    // the 10 round keys of the chain, pinned in vector registers: they are wave-uniform and loop-invariant, so the
+    // compiler would keep all 20 in SGPRs, run out, and park them in lanes of a spill VGPR -- a v_readlane and a
+    // hazard nop per round inside the growth loop.  From a VGPR the round's v_xor takes them as they are.
+    uint32_t kr0[10], kr1[10];
 };
+MC_D uint32_t pin_vgpr(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+MC_D void rng_keys(Rng& g)
+{
+    uint32_t a = g.k0, b = g.k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { g.kr0[r] = pin_vgpr(a); g.kr1[r] = pin_vgpr(b); a += kPhiloxW0; b += kPhiloxW1; }
+}
+// philox4x32_10 (device_math.hpp) with the key schedule of rng_keys
+MC_D u32x4 philox_pinned(u32x4 c, const Rng& g)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)kPhiloxM0 * c.x;
+        const uint64_t p1 = (uint64_t)kPhiloxM1 * c.z;
+        u32x4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ g.kr0[r];
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ g.kr1[r];
+        n.w = (uint32_t)p0;
+        c = n;
+    }
+    return c;
+}
 
 // rand()/RAND_MAX as one multiplication by the f64 nearest to 1/(2^32 - 1): the largest word gives 1.0
 MC_D double to_unit(uint32_t x) { return (double)x * 2.3283064370807974e-10; }
@@ -51,7 +78,7 @@ MC_D void wave_fence();
 MC_D u32x4 rng_gen(Rng& g, int batch, int lane)
 {
     u32x4 c = { g.step_lo, g.step_hi, (uint32_t)(batch * 64 + lane), kPhiloxTag };
-    u32x4 r = philox4x32_10(c, g.k0, g.k1);
+    u32x4 r = philox_pinned(c, g);
     wave_fence();
     // the divisions are done once per 256 positions, off the BFS critical path
     g.buf[lane] = to_unit(r.x); g.buf[64 + lane] = to_unit(r.y);
@@ -365,6 +392,7 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
 
     Rng g;
     g.k0 = a.seed; g.k1 = a.chain_offset + (uint32_t)chain;
+    rng_keys(g);
     g.buf = reinterpret_cast<double*>(wbase + L.w_rng);
 
     unsigned long long* marg = a.marg + (size_t)frame * a.s_max * a.lmax;
@@ -530,7 +558,8 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                 const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 3);
                 const double r_mh = g.buf[4];
                 orig = label[start];
-                // the old segment's cache row (sums, probabilityL, size): in flight during the growth
+                // the old segment's cache row (sums, probabilityL, size): in flight during the growth (a scalar load:
+                // as one vector load with lane k = entry k and v_readlane at the uses it measured 3 % slower)
                 double Co[kSegCacheUsed];
     #pragma unroll
                 for (int k = 0; k < kSegCacheUsed; ++k) Co[k] = g_segC[(size_t)orig * kSegCacheStride + k];

@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcmc_amd import host
 from mcmc_amd.scene import make_scene
-scs = [make_scene(seed=s) for s in range(1, 5)]
+seeds = [int(x) for x in os.environ.get("C5_SEEDS", "1,100,101,102").split(",")]       # the bench's four scenes
+scs = [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=s) for s in seeds]
 smax = max(s.n_superpixels for s in scs); emax = max(s.col.size for s in scs)
 ctx = host.Context()
 ctx.frames_alloc(32, smax, emax)
@@ -24,3 +25,10 @@ ctx.chains_init(2048, chains_per_frame=64, seed=5)
 for k in range(5):
     ctx.chains_run(0, 1000)
     print("measured launch %d: %.2f us per step, visit capacity %d" % (k, ctx.last_kernel_ms(3), ctx.visit_capacity()))
+
+# the bench's own sequence: moments + edge probabilities before every launch, no burn-in, no sync in between
+ctx.chains_init(2048, chains_per_frame=64, seed=5)
+for k in range(4):
+    ctx.frames_moments(); ctx.frames_edge_probs(); ctx.chains_run(0, 1000, sync=False)
+    ctx.synchronize()
+    print("bench sequence launch %d: %.2f us per step" % (k, ctx.last_kernel_ms(3)))
