@@ -303,9 +303,13 @@ def k3_bound_model(us_per_step):
     per_chain_step = (3390749429 + 1824715384 + 381802734 + 63038829) * 2 / (1024.0 * 2500.0)   # VALU + SALU + LDS + VMEM
     model_us = per_chain_step * 4.0 / 2400.0
     growth_lat = 14.96 * 4 * 65.8                  # passes x dependent LDS round trips x ds_read latency (r02_lds_latency.txt)
+    # the vector pipe alone: its instructions at the 4.8 cycles the f64 / 64-bit-multiply / lane-move mix of this
+    # kernel issues at with two waves per SIMD (profiles/r02_valu_rate_k3.txt); the scalar pipe runs beside it
+    valu_us = 3390749429 * 2 / (1024.0 * 2500.0) * 4.8 / 2400.0
     return {"kind": "instruction issue per SIMD: instructions per committed chain step x 4 cycles at 2.4 GHz, one chain per SIMD",
             "instructions_per_chain_step": per_chain_step, "cycles_per_instruction": 4.0, "model_us_per_step": model_us,
             "achieved_us_per_step": us_per_step, "frac": model_us / us_per_step,
+            "valu_pipe_only_us_per_step": valu_us, "valu_pipe_only_frac": valu_us / us_per_step,
             "growth_dependent_lds_cycles_per_step": growth_lat,
             "note": "both waves of a chain, wasted speculation included; the in-order critical path of the growth alone "
                     "(passes x 4 dependent LDS round trips x 65.8 cycles) is what a single wave per chain could not hide; "

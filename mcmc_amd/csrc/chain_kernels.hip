@@ -527,6 +527,13 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
             ts = ts_next++;
             if (ts >= total) break;
         }
+        // nothing an evaluation hands to the commit outlives its step: said here, or the compiler carries every one of
+        // these around the loop (registers and SGPR spills through the growth; 5 % of the eight-chain form's step)
+        start = 0; orig = 0; next = 0; csize = 0; qt = 0; kase = 0; st = 0; have1 = false; accept = false;
+        targetL = 0.0; prop = 0.0; R2 = 0.0; R1 = 0.0;
+        f1 = SegFit{ 0.0, 0, 0, 0 }; f2 = SegFit{ 0.0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < kSumStride; ++k) { M2[k] = 0.0; M1[k] = 0.0; }
         const unsigned long long t = a.step0 + ts;
         bool evaluated = false;
         // attempt 0: evaluate now (speculatively in the two-wave form); attempt 1 (two-wave form only): at this
