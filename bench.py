@@ -300,12 +300,12 @@ def k3_bound_model(us_per_step):
     bound is instruction issue of the SIMD: one wave-instruction per 4 cycles (tools/micro/valu_rate.hip: 2.9 - 6
     cycles by opcode with four waves per SIMD).  Instruction counts are those of profiles/r02_k3_pmc.txt
     (rocprofv3 --pmc, speculative kernel, launches of 2000 + 500 steps x 1024 chains); the step time is live."""
-    per_chain_step = (3390749429 + 1824715384 + 381802734 + 63038829) * 2 / (1024.0 * 2500.0)   # VALU + SALU + LDS + VMEM
+    per_chain_step = (3252771178 + 1776047396 + 381801841 + 63634526) * 2 / (1024.0 * 2500.0)   # VALU + SALU + LDS + VMEM
     model_us = per_chain_step * 4.0 / 2400.0
     growth_lat = 14.96 * 4 * 65.8                  # passes x dependent LDS round trips x ds_read latency (r02_lds_latency.txt)
     # the vector pipe alone: its instructions at the 4.8 cycles the f64 / 64-bit-multiply / lane-move mix of this
     # kernel issues at with two waves per SIMD (profiles/r02_valu_rate_k3.txt); the scalar pipe runs beside it
-    valu_us = 3390749429 * 2 / (1024.0 * 2500.0) * 4.8 / 2400.0
+    valu_us = 3252771178 * 2 / (1024.0 * 2500.0) * 4.8 / 2400.0
     return {"kind": "instruction issue per SIMD: instructions per committed chain step x 4 cycles at 2.4 GHz, one chain per SIMD",
             "instructions_per_chain_step": per_chain_step, "cycles_per_instruction": 4.0, "model_us_per_step": model_us,
             "achieved_us_per_step": us_per_step, "frac": model_us / us_per_step,
