@@ -607,7 +607,8 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                         const double rA = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
                         const double rB = rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), lane);
                         const uint32_t jA = colAt(eA), jB = colAt(eB);
-                        const double qA = actA ? qv[eA] : -1.0, qB = actB ? qv[eB] : -1.0;
+                        const double qxA = qv[eA], qxB = qv[eB];       // entry 0 for an idle lane: no branch around the load
+                        const double qA = actA ? qxA : -1.0, qB = actB ? qxB : -1.0;
                         const uint32_t cA = cl[jA], cB = cl[jB];
                         const uint32_t lA = label[jA], lB = label[jB];
                         const uint32_t rjA = rowp[jA], djA = rowp[jA + 1] - rjA;
@@ -667,7 +668,8 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                     const uint32_t e = act ? ent.y + s8 : 0u;
                     const double r = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
                     const uint32_t j = colAt(e);
-                    const double qe = act ? qv[e] : -1.0;
+                    const double qx = qv[e];                            // entry 0 for an idle lane: no branch around the load
+                    const double qe = act ? qx : -1.0;
                     const uint32_t cj = cl[j];
                     const uint32_t lj = label[j];
                     const uint32_t rj = rowp[j], dj = rowp[j + 1] - rj;
@@ -737,9 +739,16 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                 if (kase != 0) {
                     // cached row of the target segment (Segment::combine / diff on sums instead of a refit from
                     // the member list, Graph.cpp:35-67): issued now, needed after the pass over the component
+                    // (one branch around the whole row: written as a select per entry it became thirteen loads, each
+                    // behind a branch of its own)
                     double Cn[kSegCacheUsed];
     #pragma unroll
-                    for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = kase == 2 ? g_segC[(size_t)next * kSegCacheStride + k] : 0.0;
+                    for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = 0.0;
+                    if (kase == 2) {
+                        const double* row = g_segC + (size_t)next * kSegCacheStride;
+    #pragma unroll
+                        for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = row[k];
+                    }
                     // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
                     // Graph.cpp:10-33), wave order over the examined-edge queue
                     double ps = 1.0, pm = 1.0;
