@@ -324,7 +324,7 @@ int mcmc_mv_chains_get_planes(mcmc_mv *mv, int chain, double *out /* n_segments*
 /* Device time of the last mcmc_mv_chains_run launch, milliseconds (< 0: none). */
 /* Diagnostic (no counterpart in the reference): with option "profile" = 1 the first half of a split
  * iteration sums shader-clock cycles per phase over all chains of the last run: [0] set-up, [1] start vertex,
- * [2] growth, [3] move type / neighbour segments, [4] planes, [5] hand-over, [6] write-back, [8] growth levels,
+ * [2] growth, [3] move type / neighbour segments, [4] planes, [5] hand-over, [6] write-back, [7] the counting for [10..12] itself (not a phase of the product), [8] growth levels,
  * [9] grown vertices, [10] points in SB1 u SB2, [11] (vertex, plane) residual evaluations requested, [12] point
  * residuals requested; and the L1 kernel, summed over one item in 16: [16] cycles before the first block (item record,
  * pair list, planes), [17] cycles in the block loop, [18] cycles after it, [19] items, [20] blocks of 16 points,

@@ -420,6 +420,7 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         MVCHK(c, mvalloc(&c->ex_plist, mv_split_plist_entries(c->V, c->n))); MVCHK(c, mvalloc(&c->ex_queue, mv_split_queue_entries(c->V, c->n)));
         MVCHK(c, mvalloc(&c->ex_counters, 2));
         MVCHK(c, hipMemsetAsync(c->ex_counters, 0, 2 * sizeof(uint32_t), c->stream));
+        MVCHK(c, hipMemsetAsync(c->ex_need, 0, NV, c->stream));      // all zero between iterations (MvExchange::need)
     }
     if (c->opt_prof) {
         if (!c->d_prof) MVCHK(c, mvalloc(&c->d_prof, 32));

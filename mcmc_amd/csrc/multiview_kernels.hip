@@ -419,7 +419,8 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
 struct MvExchange {
     MvShared* sh;       // [C]
     uint8_t* inE;       // [C][V] the grown set
-    uint8_t* need;      // [V][C] bit k: the L1 residual of vertex v under plane k of this chain is wanted
+    uint8_t* need;      // [V][C] bit k: the L1 residual of vertex v under plane k of this chain is wanted; zero between
+                        // iterations (the first half writes the non-zero codes, mv_err_pairs_kernel clears them again)
     double* err;        // [C][4][V]
     uint16_t* plist;    // [chain blocks][V][4096] the pairs (chain in block << 2 | plane) that want a vertex's residual
     uint4* queue;       // [chain blocks * V * 64] items of 64 pairs: .x vertex | chain block << 16, .y item | pairs << 8,
@@ -486,7 +487,6 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         const unsigned long long t = a.step0 + ts;
         if (status != 0) {
             if (MODE != 2 && tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
-            if (MODE == 1) for (int v = tid; v < V; v += NT) x.need[(size_t)v * a.n_chains + chain] = 0;
             continue;
         }
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
@@ -601,7 +601,6 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
             for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
             if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
-            if (MODE == 1) for (int v = tid; v < V; v += NT) x.need[(size_t)v * a.n_chains + chain] = 0;
             __syncthreads();
             continue;
         }
@@ -706,27 +705,38 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
             if (MODE == 1) {
-                int prof_pts = 0, prof_ev = 0, prof_pe = 0;
                 for (int v = tid; v < V; v += NT) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
                     const uint32_t nb4 = (uint32_t)(!h0 && o == orig) | ((uint32_t)(!h1 && o == target) << 1) |
                                          ((uint32_t)(o == orig && !ie) << 2) | ((uint32_t)(o == target || ie) << 3);
-                    x.need[(size_t)v * a.n_chains + chain] = (uint8_t)nb4;
+                    // the table is all zero between iterations (mv_err_pairs_kernel clears what it reads), so only the
+                    // vertices of the sets are written: [V][C] makes these byte stores one cache line each
+                    if (nb4) x.need[(size_t)v * a.n_chains + chain] = (uint8_t)nb4;
                     x.inE[(size_t)chain * V + v] = L.inE[v];
-                    if (a.prof && (o == orig || o == target || ie)) {
-                        // points of SB1 u SB2 (the algorithmic-bytes figure of SURVEY 8d) and evaluations asked for
-                        prof_pts += (int)(g.pt_ptr[v + 1] - g.pt_ptr[v]);
-                        prof_ev += __popc(nb4);
-                        prof_pe += __popc(nb4) * (int)(g.pt_ptr[v + 1] - g.pt_ptr[v]);   // residuals |n.p + d| asked for
-                    }
                 }
                 if (a.prof) {
+                    // the profile's own counting, outside the timed phases (slot 7 takes its time): points of SB1 u SB2
+                    // (the algorithmic-bytes figure of SURVEY 8d), evaluations and residuals |n.p + d| asked for
+                    stamp(5);
+                    int prof_pts = 0, prof_ev = 0, prof_pe = 0;
+                    for (int v = tid; v < V; v += NT) {
+                        const uint32_t o = L.own[v];
+                        const bool ie = L.inE[v] != 0;
+                        const uint32_t nb4 = (uint32_t)(!h0 && o == orig) | ((uint32_t)(!h1 && o == target) << 1) |
+                                             ((uint32_t)(o == orig && !ie) << 2) | ((uint32_t)(o == target || ie) << 3);
+                        if (o == orig || o == target || ie) {
+                            prof_pts += (int)(g.pt_ptr[v + 1] - g.pt_ptr[v]);
+                            prof_ev += __popc(nb4);
+                            prof_pe += __popc(nb4) * (int)(g.pt_ptr[v + 1] - g.pt_ptr[v]);
+                        }
+                    }
                     prof_pts = wave_sum_i32(prof_pts); prof_ev = wave_sum_i32(prof_ev); prof_pe = wave_sum_i32(prof_pe);
                     if (lane == 0) {
                         atomicAdd(a.prof + 10, (unsigned long long)prof_pts); atomicAdd(a.prof + 11, (unsigned long long)prof_ev);
                         atomicAdd(a.prof + 12, (unsigned long long)prof_pe);
                     }
+                    stamp(7);
                 }
             }
             if (MODE == 0) {
@@ -790,8 +800,6 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         }
         if (MODE == 1) {
             // first half done: hand the shared block over (a skipped proposal wants no residuals)
-            if (kind == 2) for (int v = tid; v < V; v += NT) x.need[(size_t)v * a.n_chains + chain] = 0;
-            __syncthreads();
             const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
             uint32_t* dst = reinterpret_cast<uint32_t*>(x.sh + chain);
             for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel
         v = uni(g.vorder[slot]);                                       // vertices with many points first
         uint16_t* list = x.plist + ((size_t)blockIdx.y * g.V + v) * (kErrChainsPerBlock * 4);
         // lane l looks at chains c0 + 16 l .. + 15: all sixteen codes are fetched before any is used
-        const uint8_t* row = x.need + (size_t)v * n_chains;
+        uint8_t* row = x.need + (size_t)v * n_chains;
         uint32_t code[16];
         uint32_t mine = 0;
 #pragma unroll
@@ -869,6 +877,9 @@ __global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) mine += (uint32_t)__popc(code[k]);
+        // every code is read exactly once, here: cleared for the next iteration
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (code[k]) row[c0 + 16 * lane + k] = 0;
         // exclusive prefix over the lanes
         uint32_t incl = mine;
 #pragma unroll

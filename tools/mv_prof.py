@@ -22,7 +22,7 @@ print("segments per chain (mean)", float(m.scalars()["n_segments"].mean()))
 if os.environ.get("PHASES"):
     p = m.profile().astype(float)
     n = float(os.environ.get("CHAINS", 1024)) * float(os.environ.get("STEPS", 10))
-    names = ["set-up", "start", "growth", "move/neighbours", "planes", "hand-over", "write-back"]
+    names = ["set-up", "start", "growth", "move/neighbours", "planes", "hand-over", "write-back", "(the profile's own counting)"]
     for k, nm in enumerate(names):
         print(f"{nm:16s} {p[k] / n:10.0f} cycles per chain-step")
     print(f"levels {p[8] / n:.1f}  grown vertices {p[9] / n:.1f}")
