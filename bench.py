@@ -395,6 +395,8 @@ def main():
     if world > 1 or os.environ.get("MCMC_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:      # the one-rank rehearsal, started without a launcher
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from mcmc_amd import host
