@@ -160,12 +160,14 @@ MC_D void acc_add_half(Acc& s, const uint32_t m[4], const uint32_t bw[4], bool s
     cnt = udot4(p23, 0x01010101u, udot4(p01, 0x01010101u, cnt));
     kr = udot4(p23, w23, udot4(p01, w01, kr));
     s.k2 = udot4(p23, q23, udot4(p01, q01, s.k2));
-    br = sdot2(b0, kOnes, br); br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
+    if constexpr (KB == 0) br = sdot2z(b0, kOnes); else br = sdot2(b0, kOnes, br);   // the first half starts the row's totals
+    br = sdot2(b1, kOnes, br); br = sdot2(b2, kOnes, br); br = sdot2(b3, kOnes, br);
     int bk = s.bk;
     bk = sdot2(b0, (K) | ((K + 1) << 16), bk); bk = sdot2(b1, (K + 2) | ((K + 3) << 16), bk);
     bk = sdot2(b2, (K + 4) | ((K + 5) << 16), bk); bk = sdot2(b3, (K + 6) | ((K + 7) << 16), bk);
     s.bk = bk;
-    if (squares) {   // wave-uniform
+    if (squares) {   // wave-uniform: a scalar branch (the empty volatile statement keeps it from becoming a copy and a select)
+        asm volatile("");
         int q = (int)s.bb32;
         q = sdot2(b0, b0, q); q = sdot2(b1, b1, q); q = sdot2(b2, b2, q); q = sdot2(b3, b3, q);
         s.bb32 = (uint32_t)q;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
         if (emL) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, lane);
         L.lab = l0;
         // the right accumulator follows the label of the last pixel while that differs from pixel 0
-        const uint64_t emR = ballot64(evR);
+        const uint64_t emR = ballot64(two) & ballot64(l7 != Rr.lab);   // = ballot64(evR), as two compares and a scalar AND
         if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, lane);
         Rr.lab = evR ? l7 : Rr.lab;
         int cL = 0, kL = 0, brL = 0, cR = 0, kR = 0, brR = 0;
@@ -497,8 +499,10 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
         acc_add_row(L, cL, kL, brL, it, r2);
         acc_add_row(Rr, cR, kR, brR, it, r2);
         // pixels in neither, or a row whose squares were left out: queue the chunk
-        const bool rest = live && (cL + cR != NP || !squares);
-        const uint64_t rm = ballot64(rest);
+        const bool partial = live && cL + cR != NP;
+        const bool rest = partial || (live && !squares);
+        uint64_t rm = ballot64(partial);
+        if (!squares) rm = RAGGED ? ballot64(live) : ballot64(true);     // wave-uniform
         if (rm) {
             if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | (squares ? 0u : 0x8000u) | ((uint32_t)g << 16);
             qcnt += __popcll((unsigned long long)rm);
