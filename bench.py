@@ -273,6 +273,7 @@ def c5_share_line(host, sc_list, device, frames=32, cpf=64, iters=1000, steps=2)
         host.load_scene(ctx, f, sc_list[f % len(sc_list)])
     ctx.frames_moments(); ctx.frames_edge_probs()
     ctx.chains_init(frames * cpf, chains_per_frame=cpf, seed=5)
+    ctx.reserve_visits((steps + 1) * iters)      # Statistics keeps every state: room for the whole run, as in the headline job
     ctx.set_timing(True)
 
     def step():
