@@ -801,9 +801,22 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                     MC_PHASE(3);
                     const double sep = wave_prod_f64(ps);
                     const double mrg = kase == 2 ? wave_prod_f64(pm) : 1.0;
+                    // the eleven sums: the two-wave form, which is bound by instruction issue, folds them into one
+                    // butterfly (device_math.hpp: the bits of eleven wave_sum_f64 for half the instructions, two LDS
+                    // exchanges across rows; -0.6 % per step); the one-wave forms, bound by latency, measured 1 % slower
+                    // with it and keep the eleven plain ones
+                    double sums[kSumStride + 1];
     #pragma unroll
-                    for (int k = 0; k < kSumStride; ++k) mc[k] = wave_sum_f64(mc[k]);  // integer-valued: exact, order-free
-                    const double Rc = wave_sum_f64(rp);
+                    for (int k = 0; k < kSumStride; ++k) sums[k] = mc[k];
+                    sums[kSumStride] = rp;
+                    if constexpr (SPEC) wave_sum11_f64(sums, lane);
+                    else {
+    #pragma unroll
+                        for (int k = 0; k <= kSumStride; ++k) sums[k] = wave_sum_f64(sums[k]);
+                    }
+    #pragma unroll
+                    for (int k = 0; k < kSumStride; ++k) mc[k] = sums[k];
+                    const double Rc = sums[kSumStride];
                     const int minC = wave_min_i32(mn);
                     MC_PHASE(4);
     #pragma unroll

@@ -239,6 +239,53 @@ MC_D double wave_prod_f64(double v)
     const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
     return (r0 * r1) * (r2 * r3);
 }
+// ---- several sums at once ----
+// wave_sum_f64 of up to sixteen values, bit for bit, for about half the instructions: a stage of the butterfly halves
+// the number of registers instead of repeating itself in every lane.  Values a and b meet at a stage whose partner
+// differs in lane bit k: lanes with the bit clear keep a and hand b over, lanes with it set keep b and hand a over, and
+// own + received is the same addition the plain butterfly does in that lane (its partner holds the mirror image).  After
+// the stages xor 1, 2, 4, 8 lane p of every row holds the row's sum of value p; two exchanges across rows give
+// (r0 + r1) + (r2 + r3) everywhere, and value k is read from lane k.  The exchanges must pair lane l with l ^ 2^k exactly
+// (the mirrors of wave_sum_f64 will not do: the partner has to hold the same value), so xor 4 is two rotations with
+// complementary bank masks, xor 8 a rotation by 8, and the rows use ds_bpermute.
+template <int CTRL, int BANK>
+MC_D double dpp_f64_banks(double old, double v)
+{
+    const uint64_t u = d2u(v), o = d2u(old);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)u, CTRL, 0xf, BANK, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(u >> 32), CTRL, 0xf, BANK, false);
+    return u2d(((uint64_t)hi << 32) | lo);
+}
+template <int STAGE>
+MC_D double xchg_f64(double v)
+{
+    if constexpr (STAGE == 0) return dpp_f64<0xB1>(v);                  // l ^ 1: quad_perm [1,0,3,2]
+    else if constexpr (STAGE == 1) return dpp_f64<0x4E>(v);             // l ^ 2: quad_perm [2,3,0,1]
+    else if constexpr (STAGE == 2)                                      // l ^ 4: lanes 4-7, 12-15 read l - 4 (row_ror:4),
+        return dpp_f64_banks<0x12C, 0x5>(dpp_f64_banks<0x124, 0xA>(v, v), v);   // lanes 0-3, 8-11 read l + 4 (row_ror:12)
+    else return dpp_f64<0x128>(v);                                      // l ^ 8: row_ror:8
+}
+// one stage: the pair (a, b) becomes one register
+template <int STAGE>
+MC_D double fold_f64(double a, double b, int lane)
+{
+    const bool hi = (lane >> STAGE) & 1;
+    const double keep = hi ? b : a, send = hi ? a : b;
+    return keep + xchg_f64<STAGE>(send);
+}
+// v[0..10] -> their wave sums (every lane gets all eleven)
+MC_D void wave_sum11_f64(double (&v)[11], int lane)
+{
+    const double w0 = fold_f64<0>(v[0], v[1], lane), w1 = fold_f64<0>(v[2], v[3], lane), w2 = fold_f64<0>(v[4], v[5], lane),
+                 w3 = fold_f64<0>(v[6], v[7], lane), w4 = fold_f64<0>(v[8], v[9], lane), w5 = fold_f64<0>(v[10], 0.0, lane);
+    const double u0 = fold_f64<1>(w0, w1, lane), u1 = fold_f64<1>(w2, w3, lane), u2 = fold_f64<1>(w4, w5, lane);
+    const double t0 = fold_f64<2>(u0, u1, lane), t1 = fold_f64<2>(u2, 0.0, lane);
+    double r = fold_f64<3>(t0, t1, lane);
+    r = r + __shfl_xor(r, 16, kWave);
+    r = r + __shfl_xor(r, 32, kWave);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) v[k] = readlane_f64(r, k);
+}
 MC_D uint64_t wave_sum_u64(uint64_t v)
 {
 #pragma unroll
