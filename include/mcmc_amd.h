@@ -192,6 +192,12 @@ int mcmc_chains_get_profile(mcmc_ctx *ctx, uint64_t *out16);
 int mcmc_selftest_math(mcmc_ctx *ctx, const double *x, const double *y, int n, double *out_log,
                        double *out_exp, double *out_div);
 int mcmc_selftest_philox(mcmc_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* Device self-test of the wave reductions the chain kernel sums with (no counterpart in the reference: its sums are
+ * sequential loops, Segmentation.cpp:127-146; the order here is the fixed xor butterfly of DESIGN.md section 3 that the
+ * oracle mirrors).  x holds n_waves * 11 * 64 values, [wave][value][lane]; out_plain[wave][value] = the butterfly sum
+ * taken one value at a time, out_folded[wave][value] = the same sums from the folded form that takes eleven at once.
+ * Both must equal the butterfly computed on the host, bit for bit. */
+int mcmc_selftest_wave_sums(mcmc_ctx *ctx, const double *x, int n_waves, double *out_plain, double *out_folded);
 
 /* ======================================================================== *
  * Over-segmentation front end: the producer of the

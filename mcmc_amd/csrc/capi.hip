@@ -815,6 +815,21 @@ int mcmc_selftest_math(mcmc_ctx* c, const double* x, const double* y, int n, dou
     return MCMC_OK;
 }
 
+int mcmc_selftest_wave_sums(mcmc_ctx* c, const double* x, int n_waves, double* out_plain, double* out_folded)
+{
+    if (!c || !x || n_waves <= 0 || n_waves > 65535 || !out_plain || !out_folded) return fail(c, MCMC_E_BADARG, "selftest_wave_sums: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t NI = (size_t)n_waves * 11 * 64, NO = (size_t)n_waves * 11;
+    if (c->self_cap < NI + 2 * NO) { dfree(c->d_self); HIPCHK(c, dalloc(&c->d_self, NI + 2 * NO)); c->self_cap = NI + 2 * NO; }
+    double* d = c->d_self;
+    HIPCHK(c, hipMemcpyAsync(d, x, NI * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_selftest_wave_sums(d, n_waves, d + NI, d + NI + NO, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_plain, d + NI, NO * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_folded, d + NI + NO, NO * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCMC_OK;
+}
+
 int mcmc_selftest_philox(mcmc_ctx* c, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     if (!c || !ctr || !key || !out) return fail(c, MCMC_E_BADARG, "selftest_philox: bad argument");

@@ -724,6 +724,21 @@ __global__ void selftest_math_kernel(const double* x, const double* y, int n, do
     oe[i] = det_exp(x[i]);
     od[i] = x[i] / y[i];
 }
+// one wave per block: eleven wave_sum_f64 and one wave_sum11_f64 of the same values
+__global__ __launch_bounds__(64) void selftest_wave_sums_kernel(const double* x, double* plain, double* folded)
+{
+    const int lane = (int)threadIdx.x, b = (int)blockIdx.x;
+    double v[11], w[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { v[k] = x[((size_t)b * 11 + k) * 64 + lane]; w[k] = wave_sum_f64(v[k]); }
+    wave_sum11_f64(v, lane);
+    if (lane < 11) {
+        double pw = 0.0, fv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) if (lane == k) { pw = w[k]; fv = v[k]; }
+        plain[(size_t)b * 11 + lane] = pw; folded[(size_t)b * 11 + lane] = fv;
+    }
+}
 __global__ void selftest_philox_kernel(const uint32_t* ck, uint32_t* out)
 {
     u32x4 c = { ck[0], ck[1], ck[2], ck[3] };
@@ -820,6 +835,11 @@ hipError_t launch_mark_members(const uint32_t* list, int n, uint8_t* mem, hipStr
 hipError_t launch_selftest_math(const double* x, const double* y, int n, double* ol, double* oe, double* od, hipStream_t st)
 {
     hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 127) / 128), dim3(128), 0, st, x, y, n, ol, oe, od);
+    return hipGetLastError();
+}
+hipError_t launch_selftest_wave_sums(const double* x, int n_waves, double* plain, double* folded, hipStream_t st)
+{
+    hipLaunchKernelGGL(selftest_wave_sums_kernel, dim3(n_waves), dim3(64), 0, st, x, plain, folded);
     return hipGetLastError();
 }
 hipError_t launch_selftest_philox(const uint32_t* ck, uint32_t* out, hipStream_t st)

@@ -102,6 +102,7 @@ hipError_t launch_segment_prob(const SegArgs& a, hipStream_t st);
 hipError_t launch_mark_members(const uint32_t* list, int n, uint8_t* mem, hipStream_t st);  // list ids < size of mem (checked by the caller)
 hipError_t launch_selftest_math(const double* x, const double* y, int n, double* ol, double* oe, double* od, hipStream_t st);
 hipError_t launch_selftest_philox(const uint32_t* ck, uint32_t* out, hipStream_t st);
+hipError_t launch_selftest_wave_sums(const double* x, int n_waves, double* plain, double* folded, hipStream_t st);
 
 // chain kernel: returns hipErrorInvalidValue if the per-chain state does not fit LDS
 hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st);

@@ -100,6 +100,7 @@ def load():
         "mcmc_chains_get_profile": (i, [vp, vp]),
         "mcmc_selftest_math": (i, [vp, vp, vp, i, vp, vp, vp]),
         "mcmc_selftest_philox": (i, [vp, vp, vp, vp]),
+        "mcmc_selftest_wave_sums": (i, [vp, vp, i, vp, vp]),
         "mcmc_mv_create": (i, [i, C.POINTER(vp)]),
         "mcmc_mv_destroy": (i, [vp]),
         "mcmc_mv_last_error": (C.c_char_p, [vp]),
@@ -342,6 +343,15 @@ class Context:
         self._ck(self.L.mcmc_selftest_math(self.h, _ptr(x, np.float64), _ptr(y, np.float64), x.size,
                                            _ptr(ol, np.float64), _ptr(oe, np.float64), _ptr(od, np.float64)))
         return ol, oe, od
+
+    def selftest_wave_sums(self, x):
+        """x[n_waves][11][64] -> (plain, folded), each [n_waves][11]: the chain kernel's wave sums, both forms."""
+        x = np.ascontiguousarray(x, np.float64)
+        assert x.ndim == 3 and x.shape[1:] == (11, 64)
+        plain = np.zeros((x.shape[0], 11)); folded = np.zeros((x.shape[0], 11))
+        self._ck(self.L.mcmc_selftest_wave_sums(self.h, _ptr(x, np.float64), x.shape[0], _ptr(plain, np.float64),
+                                                _ptr(folded, np.float64)))
+        return plain, folded
 
     def selftest_philox(self, ctr, key):
         ctr = np.ascontiguousarray(ctr, np.uint32); key = np.ascontiguousarray(key, np.uint32)

@@ -28,6 +28,22 @@ def bits(a):
     return np.ascontiguousarray(a, np.float64).view(np.uint64)
 
 
+def test_wave_sums_bit_exact(gpu_ctx_factory):
+    """The chain kernel's wave reductions, one value at a time and eleven at once (the folded butterfly of the two-wave
+    form), against the oracle's butterfly (oracle/mcmc_oracle.c: wave_sum) on inexact doubles of mixed magnitude."""
+    ctx = gpu_ctx_factory()
+    rng = np.random.default_rng(11)
+    n = 300
+    x = np.ldexp(rng.uniform(-0.5, 0.5, (n, 11, 64)), rng.integers(-20, 20, (n, 11, 64)))
+    x[rng.random(x.shape) < 0.2] = 0.0
+    x[0] = 0.0; x[1, :, 1:] = 0.0           # empty wave; one lane only
+    plain, folded = ctx.selftest_wave_sums(x)
+    L = O.lib()
+    want = np.array([[L.orc_wave_sum(np.ascontiguousarray(x[w, k])) for k in range(11)] for w in range(n)])
+    assert np.array_equal(bits(plain), bits(want))
+    assert np.array_equal(bits(folded), bits(want))
+
+
 def test_device_math_bit_exact(gpu_ctx_factory):
     ctx = gpu_ctx_factory()
     rng = np.random.default_rng(1)
