@@ -18,7 +18,7 @@ ctx.chains_init(2048, chains_per_frame=64, seed=5)
 r = []
 for k in range(4):
     ctx.chains_run(0, 1000); r.append(ctx.last_kernel_ms(3))
-print(os.path.basename(os.getcwd()), "c5 share variant", ctx.last_variant(), " ".join("%.2f" % x for x in r))
+print(os.path.basename(os.getcwd()), "c5 share, variant", ctx.last_variant(), " ".join("%.2f" % x for x in r))
 ctx.close()
 ctx = host.Context()
 ctx.frames_alloc(1, scs[0].n_superpixels, scs[0].col.size)
@@ -28,4 +28,4 @@ ctx.chains_init(1024, chains_per_frame=1024, seed=1)
 r = []
 for k in range(4):
     ctx.chains_run(0, 2000); r.append(ctx.last_kernel_ms(3) / 2)
-print(os.path.basename(os.getcwd()), "c2 one wave variant", ctx.last_variant(), " ".join("%.2f" % x for x in r))
+print(os.path.basename(os.getcwd()), "c2, 1024 chains, variant", ctx.last_variant(), " ".join("%.2f" % x for x in r))
