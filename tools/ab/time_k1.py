@@ -16,3 +16,9 @@ ms = []
 for _ in range(30):
     ctx.frames_moments(); ms.append(ctx.last_kernel_ms(host.K_MOMENTS))
 print(os.path.basename(os.getcwd()), "K1 us per 256-frame launch: mean %.2f min %.2f" % (np.mean(ms) * 1e3, np.min(ms) * 1e3))
+ctx.set_option("k1_debug", 1)
+sm = []
+for _ in range(5): ctx.frames_moments()
+for _ in range(20):
+    ctx.frames_moments(); sm.append(ctx.last_kernel_ms(host.K_MOMENTS))
+print(os.path.basename(os.getcwd()), "K1 loads only (k1_debug): mean %.2f min %.2f" % (np.mean(sm) * 1e3, np.min(sm) * 1e3))
