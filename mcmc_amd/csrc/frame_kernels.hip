@@ -437,7 +437,6 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     }
 #pragma unroll
     for (int k = 0; k < NSET; ++k) load_row(k, sets[k]);
-    int r2 = 0;
     uint32_t sink = 0;
     auto row = [&](const int it, RowSet<NQ>& rr) __attribute__((always_inline)) {
         if constexpr (STREAM) {
@@ -447,10 +446,6 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
                 sink |= (rr.d[q].x | rr.d[q].y) | (rr.d[q].z | rr.d[q].w) | (rr.l[q].x | rr.l[q].y) | (rr.l[q].z | rr.l[q].w);
             load_row(it + NSET, rr);
             return;
-        }
-        if (__builtin_expect(qcnt > kQueueCap - 64, 0)) {
-            queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, lane);
-            qcnt = 0;
         }
         wait_vm<WAITN>(rr);
         uint32_t lw[4 * NQ], dw[4 * NQ];
@@ -488,12 +483,14 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
 
         // the left accumulator follows the label of pixel 0: when that changes, the running sums are logged
         // with both labels (added to the old one, subtracted from the new one)
-        const uint64_t emL = ballot64(evL);
-        if (emL) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, lane);
-        L.lab = l0;
         // the right accumulator follows the label of the last pixel while that differs from pixel 0
+        const uint64_t emL = ballot64(evL);
         const uint64_t emR = ballot64(two) & ballot64(l7 != Rr.lab);   // = ballot64(evR), as two compares and a scalar AND
-        if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, lane);
+        if (emL | emR) {     // one branch on the common path
+            if (emL) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, lane);
+            if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, lane);
+        }
+        L.lab = l0;
         Rr.lab = evR ? l7 : Rr.lab;
         int cL = 0, kL = 0, brL = 0, cR = 0, kR = 0, brR = 0;
         const bool squares = wide == 0;
@@ -503,6 +500,7 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
             acc_add_half<8>(L, mL + 4, bL + 4, squares, cL, kL, brL);
             acc_add_half<8>(Rr, mR + 4, bR + 4, squares, cR, kR, brR);
         }
+        const int r2 = it * it;       // wave-uniform: one scalar multiply
         acc_add_row(L, cL, kL, brL, it, r2);
         acc_add_row(Rr, cR, kR, brR, it, r2);
         // pixels in neither, or a row whose squares were left out: queue the chunk
@@ -511,10 +509,14 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
         uint64_t rm = ballot64(partial);
         if (!squares) rm = RAGGED ? ballot64(live) : ballot64(true);     // wave-uniform
         if (rm) {
+            // room for this row's chunks (checked here, where the queue is written, not once per row)
+            if (__builtin_expect(qcnt + __popcll((unsigned long long)rm) > kQueueCap, 0)) {
+                queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, lane);
+                qcnt = 0;
+            }
             if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | (squares ? 0u : 0x8000u) | ((uint32_t)g << 16);
             qcnt += __popcll((unsigned long long)rm);
         }
-        r2 += 2 * it + 1;
     };
     for (int it = 0; it < R; it += NSET) {
         bool done = false;
