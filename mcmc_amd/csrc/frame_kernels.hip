@@ -364,7 +364,7 @@ MC_D uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // STREAM (measurement only, option "k1_debug" = 1): the same launch shape, loads and waits with the arithmetic
 // replaced by an OR of the words read -- the rate this access pattern reaches on its own (bench.py reports it
 // beside the kernel's rate as roofline.stream_only_GBps).  It writes no moments.
-template <int NQ, bool TABLE_LDS, bool RAGGED, bool STREAM = false, int NSET = 4>
+template <int NQ, bool TABLE_LDS, bool RAGGED, bool STREAM = false, int NSET = 3>
 __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(MomentArgs a)
 {
     constexpr int NP = 8 * NQ;                 // pixels per lane and row; NSET = row sets in flight
@@ -406,10 +406,11 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     acc_reset(Rr, kFlushR);
     int cnt = 0, qcnt = 0;     // wave-uniform
 
-    // NSET register sets hold the rows it .. it+3 of the strip.  The loads are issued by hand and
+    // NSET register sets hold the rows it .. it+NSET-1 of the strip (three: with non-temporal loads two to three rows in
+    // flight measured 1.5 % faster than four, five and six slower; tools/ab).  The loads are issued by hand and
     // waited for with counted s_waitcnt (in-order return): a set is reloaded with row it+4 as soon as its
     // words have been consumed, and a row only waits until all but the younger loads have landed,
-    // so 6-8 KB (NQ = 1) or 12-16 KB (NQ = 2) per wave stay in flight under the arithmetic.  Every load is issued
+    // so 4-6 KB (NQ = 1) or 8-12 KB (NQ = 2) per wave stay in flight under the arithmetic.  Every load is issued
     // by every wave (row index clamped per lane; the last reloads re-read the strip's last row), otherwise the
     // count of younger loads would not be the constant the wait relies on.
     const int cl = max(count, 1);
