@@ -12,7 +12,10 @@ for f in range(256):
     sc = scs[f % 4]; ctx.frame_upload(f, sc.disp, sc.label, sc.n_superpixels)
 ctx.set_timing(True)
 ref = None
-for bands, threads in ((0, 0), (2, 480), (2, 960), (1, 480), (2, 640), (3, 320), (4, 240), (1, 800), (1, 640)):
+shapes = ((0, 0), (2, 480), (2, 960), (1, 480), (2, 640), (3, 320), (4, 240), (1, 800), (1, 640))
+if os.environ.get("SHAPES"):      # e.g. SHAPES=1x960,1x800,1x640,1x960,1x800,1x640
+    shapes = tuple(tuple(int(v) for v in x.split("x")) for x in os.environ["SHAPES"].split(","))
+for bands, threads in shapes:
     ctx.set_option("k1_bands", bands); ctx.set_option("k1_threads", threads)
     for _ in range(4): ctx.frames_moments()
     ms = []
