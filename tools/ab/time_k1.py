@@ -11,9 +11,9 @@ ctx.frames_alloc(256, smax, 8)
 for f in range(256):
     sc = scs[f % 4]; ctx.frame_upload(f, sc.disp, sc.label, sc.n_superpixels)
 ctx.set_timing(True)
-for _ in range(5): ctx.frames_moments()
+for _ in range(150): ctx.frames_moments()      # clock warm-up (k1_warm.py)
 ms = []
-for _ in range(30):
+for _ in range(50):
     ctx.frames_moments(); ms.append(ctx.last_kernel_ms(host.K_MOMENTS))
 print(os.path.basename(os.getcwd()), "K1 us per 256-frame launch: mean %.2f min %.2f" % (np.mean(ms) * 1e3, np.min(ms) * 1e3))
 ctx.set_option("k1_debug", 1)
