@@ -225,9 +225,9 @@ const char *mcmc_overseg_last_error(const mcmc_overseg *os);
 /* overSegment steps 1-4 (OverSegmentation.cpp:25-48): cross-bilateral filter of
  * the colours by the disparities (:304-391), 4 edges per pixel weighted by
  * colour, disparity and distance (:236-301), Felzenszwalb-Huttenlocher
- * union-find over the sorted edges (segment-graph.h:47-111: the sort on the device,
- * equal weights in creation order, see mcmc_overseg_set_option; the sequential scan
- * on the host, as in the reference), createSuperPixels (:89-194: dense labels in ascending root
+ * union-find over the sorted edges (segment-graph.h:47-111: std::sort and the sequential scan
+ * on the host, as in the reference; option "tie_order" = 0 sorts on the device instead, see
+ * mcmc_overseg_set_option), createSuperPixels (:89-194: dense labels in ascending root
  * pixel order = the std::map order, neighbours through LEFT / TOP / TOP-RIGHT
  * contacts).  colors: H*W*3 bytes in cv::Vec3b order (B, G, R); disp: H*W shorts.
  * Errors: MCMC_E_BADARG for non-positive deviations (the reference throws,
@@ -237,9 +237,11 @@ int mcmc_overseg_run(mcmc_overseg *os, const uint8_t *colors, const int16_t *dis
                      const mcmc_overseg_params *params, int *n_superpixels, uint32_t *n_directed_edges);
 /* "tie_order": the order of edges of EQUAL weight in segment_graph's scan.  The reference sorts with std::sort on
  * the weight alone (segment-graph.h:35-37,53), which leaves equal weights wherever that standard library's
- * introsort happens to put them.  0 (default): creation order (stable; sorted on the device) -- a canonical order
- * like the others of this library; 1: std::sort of this library's C++ runtime on the host over the edges in
- * creation order, i.e. what the reference's binary does when built with the same runtime (slower). */
+ * introsort happens to put them; equal weights are common (colour and disparity distances come from integers).
+ * 1 (default): that very call -- std::sort of this library's C++ runtime on the host over the edges in creation
+ * order, i.e. what the reference's binary does when built with the same runtime; 0: stable radix sort on the device
+ * (rocPRIM, a library sort), equal weights in creation order -- faster (0.4 ms against ~35 ms at 640x480), but a
+ * superpixel layout of this library's own wherever weights tie; mcmc_overseg_last_tie_count says how many did. */
 int mcmc_overseg_set_option(mcmc_overseg *os, const char *name, int value);
 /* Results of the last run.  The device buffers (int16 disparities, uint16 labels)
  * can be handed to mcmc_frame_upload_device, the graph to mcmc_frame_set_graph. */
@@ -250,6 +252,9 @@ int mcmc_overseg_get_labels(mcmc_overseg *os, uint16_t *out /* H*W */);
 int mcmc_overseg_get_graph(mcmc_overseg *os, uint32_t *row_ptr /* S+1 */, uint32_t *col /* e2 */);
 int mcmc_overseg_device_buffers(mcmc_overseg *os, const void **d_disp, const void **d_label);
 int mcmc_overseg_last_ms(mcmc_overseg *os, float *filter_ms, float *edges_ms, float *union_find_ms, float *graph_ms);
+/* Diagnostic (no counterpart in the reference): edges of the last run whose weight equals that of the edge before
+ * them in scan order, i.e. how much of the scan order the tie rule decided (< 0: no run yet). */
+long long mcmc_overseg_last_tie_count(mcmc_overseg *os);
 /* Diagnostic (no counterpart in the reference): the two parts of union_find_ms that are not transfers --
  * the device sort and the host scan. */
 int mcmc_overseg_last_sort_ms(mcmc_overseg *os, float *device_sort_ms, float *host_scan_ms);

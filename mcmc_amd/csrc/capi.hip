@@ -213,7 +213,9 @@ int mcmc_ctx_create(int device, const mcmc_params* params, mcmc_ctx** out)
     *out = nullptr;
     mcmc_params p;
     if (params) p = *params; else mcmc_default_params(&p);
-    if (p.width <= 0 || p.height <= 0 || p.width > 4096 || p.height > 4096 || !(p.disparity_variance > 0.0) ||
+    // the variance may be +inf or NaN: both only reach the reference's own error paths (Graph.cpp:134-137), which
+    // the chains then report as the reference does; zero or negative is refused
+    if (p.width <= 0 || p.height <= 0 || p.width > 4096 || p.height > 4096 || p.disparity_variance <= 0.0 ||
         !(p.new_segment_prob >= 0.0 && p.new_segment_prob <= 1.0) || p.marginal_bins < 1 || p.visit_capacity < 0)
         return MCMC_E_BADARG;
     int ndev = 0;

@@ -8,12 +8,13 @@
 //
 // The filter and the edge weights are stencils over the frame (one 16x16 tile per workgroup, the tile
 // of disparities and colours in LDS, the disparity Gaussian from an LDS table because disparities are
-// integers).  The edges are sorted on the device (stable radix sort of the weight bits: equal weights stay in
-// creation order -- the reference sorts with std::sort on the weight alone, so there the order of equal weights
-// is whatever that standard library's introsort leaves; option "tie_order" = 1 runs that sort on the host
-// instead); the union-find pass is a sequential scan over the sorted edges and runs on the host, as in the
-// reference; labels and the neighbour relation are built on the device from the roots (rank of root pixels,
-// S x S bit matrix, CSR by row).
+// integers).  The reference sorts the edges with std::sort on the weight alone, so the order of equal weights is
+// whatever that standard library's introsort leaves: the default ("tie_order" = 1) runs that very call on the host
+// over the edges in creation order.  Option "tie_order" = 0 sorts on the device instead (stable radix sort of the
+// weight bits by rocPRIM, a library sort: equal weights stay in creation order), which is faster but is a layout
+// of this library's own wherever weights tie.  The union-find pass is a sequential scan over the sorted edges and
+// runs on the host, as in the reference; labels and the neighbour relation are built on the device from the roots
+// (rank of root pixels, S x S bit matrix, CSR by row).
 // Restates behaviour, not code; every quirk kept is listed in DESIGN.md.
 #include <cstring>
 #include <hip/hip_runtime.h>
@@ -242,41 +243,28 @@ __global__ void fill_col_kernel(const uint32_t* bits, int S, int words, const ui
     }
 }
 
-// segment_graph on the host (segment-graph.h:47-111; disjoint-set.h:42-79)
+// segment_graph on the host (segment-graph.h:47-111; disjoint-set.h:42-79): one scan over edges that are already
+// in order.  Same sets and same roots as the reference's universe (union by rank, ties to the second root,
+// disjoint-set.h:68-79): find() here halves the path instead of re-linking only the queried element (:58-64), which
+// changes how fast a root is reached, not which; a set's threshold, size and rank sit in one record at its root.
 struct WEdge { float w; int32_t a, b; };
-struct Forest {
-    std::vector<int32_t> parent, rank, size;
-    explicit Forest(int n) : parent((size_t)n), rank((size_t)n, 0), size((size_t)n, 1) { for (int i = 0; i < n; ++i) parent[(size_t)i] = i; }
-    int find(int x) { int y = x; while (y != parent[(size_t)y]) y = parent[(size_t)y]; parent[(size_t)x] = y; return y; }
-    void join(int x, int y)
-    {
-        if (rank[(size_t)x] > rank[(size_t)y]) { parent[(size_t)y] = x; size[(size_t)x] += size[(size_t)y]; }
-        else { parent[(size_t)x] = y; size[(size_t)y] += size[(size_t)x]; if (rank[(size_t)x] == rank[(size_t)y]) rank[(size_t)y]++; }
-    }
-};
-
-// The scan over edges that are already in order: slot s is the edge of pixel s / 4 in direction s % 4
-// (RIGHT, BOTTOM, BOTTOM-RIGHT, TOP-RIGHT), its weight comes back out of the sort key.  Same sets and same roots as
-// the reference's universe (union by rank, ties to the second root, disjoint-set.h:68-79): find() here halves the
-// path instead of re-linking only the queried element (:58-64), which changes how fast a root is reached, not which.
 struct FhNode { float thr; int32_t size, rank; };
-int segment_graph_sorted(int nv, int W, const uint32_t* slot, const uint32_t* key, size_t ne, float c, int32_t* root)
+// edge(e, a, b, w): endpoints and weight of the e-th edge of the scan
+// first(e): first endpoint of the e-th edge (prefetch of its parent link, 16 edges ahead)
+template <class EdgeAt, class First>
+int fh_scan(int nv, size_t ne, float c, int32_t* root, EdgeAt edge, First first)
 {
     std::vector<int32_t> p((size_t)nv);
     std::vector<FhNode> nd((size_t)nv, FhNode{ c / 1, 1, 0 });
     for (int i = 0; i < nv; ++i) p[(size_t)i] = i;
     auto find = [&](int x) { while (p[(size_t)x] != x) { const int g = p[(size_t)p[(size_t)x]]; p[(size_t)x] = g; x = g; } return x; };
     int sets = nv;
-    const int off[4] = { 1, W, W + 1, 1 - W };
     for (size_t e = 0; e < ne; ++e) {
-        if (e + 16 < ne) __builtin_prefetch(&p[slot[e + 16] >> 2]);
-        const int a = (int)(slot[e] >> 2), b = a + off[slot[e] & 3u];
+        if (e + 16 < ne) __builtin_prefetch(&p[(size_t)first(e + 16)]);
+        int a, b; float w;
+        edge(e, a, b, w);
         const int ra = find(a), rb = find(b);
         if (ra == rb) continue;
-        const uint32_t kb = key[e];
-        const uint32_t bits = (kb & 0x80000000u) ? (kb & 0x7FFFFFFFu) : ~kb;
-        float w;
-        std::memcpy(&w, &bits, 4);
         FhNode& na = nd[(size_t)ra];
         FhNode& nb = nd[(size_t)rb];
         if (w <= na.thr && w <= nb.thr) {
@@ -291,24 +279,31 @@ int segment_graph_sorted(int nv, int W, const uint32_t* slot, const uint32_t* ke
     return sets;
 }
 
-int segment_graph_host(int nv, std::vector<WEdge>& edges, float c, int32_t* root)
+// Edges sorted on the device: slot s is the edge of pixel s / 4 in direction s % 4 (RIGHT, BOTTOM, BOTTOM-RIGHT,
+// TOP-RIGHT), its weight comes back out of the sort key.
+int segment_graph_sorted(int nv, int W, const uint32_t* slot, const uint32_t* key, size_t ne, float c, int32_t* root, long long* n_ties)
+{
+    long long ties = 0;
+    for (size_t e = 1; e < ne; ++e) ties += key[e] == key[e - 1];
+    if (n_ties) *n_ties = ties;
+    const int off[4] = { 1, W, W + 1, 1 - W };
+    return fh_scan(nv, ne, c, root, [&](size_t e, int& a, int& b, float& w) {
+        a = (int)(slot[e] >> 2); b = a + off[slot[e] & 3u];
+        const uint32_t kb = key[e];
+        const uint32_t bits = (kb & 0x80000000u) ? (kb & 0x7FFFFFFFu) : ~kb;
+        std::memcpy(&w, &bits, 4);
+    }, [&](size_t e) { return (int)(slot[e] >> 2); });
+}
+
+// The reference's own order: std::sort on the weight alone (segment-graph.h:35-37,53) over the edges in creation order.
+int segment_graph_host(int nv, std::vector<WEdge>& edges, float c, int32_t* root, long long* n_ties)
 {
     std::sort(edges.begin(), edges.end(), [](const WEdge& x, const WEdge& y) { return x.w < y.w; });
-    Forest f(nv);
-    std::vector<float> thr((size_t)nv, c / 1);
-    int sets = nv;
-    for (const WEdge& e : edges) {
-        const int ra = f.find(e.a), rb = f.find(e.b);
-        if (ra == rb) continue;
-        if (e.w <= thr[(size_t)ra] && e.w <= thr[(size_t)rb]) {
-            f.join(ra, rb);
-            --sets;
-            const int r = f.find(ra);
-            thr[(size_t)r] = e.w + c / (float)(size_t)f.size[(size_t)r];
-        }
-    }
-    for (int k = 0; k < nv; ++k) root[k] = f.find(k);
-    return sets;
+    long long ties = 0;
+    for (size_t e = 1; e < edges.size(); ++e) ties += edges[e].w == edges[e - 1].w;
+    if (n_ties) *n_ties = ties;
+    return fh_scan(nv, edges.size(), c, root, [&](size_t e, int& a, int& b, float& w) { a = edges[e].a; b = edges[e].b; w = edges[e].w; },
+                   [&](size_t e) { return (int)edges[e].a; });
 }
 
 }  // namespace
@@ -331,7 +326,8 @@ struct mcmc_overseg {
     void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint32_t *p_key = nullptr, *p_idx = nullptr; int32_t* p_root = nullptr;
     hipEvent_t ev[6] = {};
-    int opt_tie_order = 0;            // 0: equal weights in creation order (device sort); 1: std::sort on the host
+    int opt_tie_order = 1;            // 1: std::sort on the host, the reference's own call (default); 0: device sort, equal weights in creation order
+    long long n_ties = 0;             // edges of the last run whose weight equals their predecessor's in scan order
     // results of the last run (host)
     std::vector<uint32_t> h_rowp, h_col;
     int S = 0; uint32_t e2 = 0;
@@ -492,7 +488,7 @@ int mcmc_overseg_run(mcmc_overseg* o, const uint8_t* colors, const int16_t* disp
         if (st[0]) return ofail(o, MCMC_E_RANGE, "overseg_run: filtered channel value outside 0..255");   // "Weird channel value."
         (void)hipEventElapsedTime(&o->ms_sort, e2, e5);
         const auto t1 = std::chrono::steady_clock::now();
-        segment_graph_sorted((int)N, W, o->p_idx, o->p_key, (size_t)st[2], (float)(size_t)p.weight_threshold, o->p_root);
+        segment_graph_sorted((int)N, W, o->p_idx, o->p_key, (size_t)st[2], (float)(size_t)p.weight_threshold, o->p_root, &o->n_ties);
         o->ms_scan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count();
     } else {
         // ---- 3'. the reference's own order of equal weights: std::sort on the host over the edges in creation order
@@ -509,7 +505,7 @@ int mcmc_overseg_run(mcmc_overseg* o, const uint8_t* colors, const int16_t* disp
         for (size_t s = 0; s < N * 4; ++s)
             if (ta[s] >= 0) edges.push_back(WEdge{ tw[s], ta[s], tb[s] });
         const auto t1 = std::chrono::steady_clock::now();
-        segment_graph_host((int)N, edges, (float)(size_t)p.weight_threshold, o->p_root);
+        segment_graph_host((int)N, edges, (float)(size_t)p.weight_threshold, o->p_root, &o->n_ties);
         o->ms_scan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count();
         o->ms_sort = 0.f;
     }
@@ -625,6 +621,12 @@ int mcmc_overseg_last_ms(mcmc_overseg* o, float* filter_ms, float* edges_ms, flo
     if (union_find_ms) *union_find_ms = o->ms_fh;
     if (graph_ms) *graph_ms = o->ms_graph;
     return MCMC_OK;
+}
+
+long long mcmc_overseg_last_tie_count(mcmc_overseg* o)
+{
+    if (!o || !o->have) return ofail(o, MCMC_E_STATE, "overseg_last_tie_count: run first");
+    return o->n_ties;
 }
 
 int mcmc_overseg_last_sort_ms(mcmc_overseg* o, float* device_sort_ms, float* host_scan_ms)

@@ -136,6 +136,7 @@ def load():
         "mcmc_overseg_last_ms": (i, [vp] + [C.POINTER(C.c_float)] * 4),
         "mcmc_overseg_last_sort_ms": (i, [vp] + [C.POINTER(C.c_float)] * 2),
         "mcmc_overseg_set_option": (i, [vp, C.c_char_p, i]),
+        "mcmc_overseg_last_tie_count": (C.c_longlong, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -581,6 +582,11 @@ class OverSegmenter:
         out["device_sort"], out["host_scan"] = g[0].value, g[1].value
         return out
 
+    def tie_count(self):
+        """Edges of the last run whose weight equals their predecessor's in scan order."""
+        return int(self.L.mcmc_overseg_last_tie_count(self.h))
+
     def set_option(self, name, value):
-        """"tie_order": 0 = equal weights in creation order (device sort, default), 1 = std::sort on the host."""
+        """"tie_order": 1 = std::sort on the host, the reference's call (default); 0 = device sort, equal weights in
+        creation order (faster; a layout of this library's own wherever weights tie)."""
         self._ck(self.L.mcmc_overseg_set_option(self.h, name.encode(), int(value)))

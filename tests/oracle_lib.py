@@ -276,7 +276,7 @@ def create_edges(disp, smoothed, color_factor=1.0, disparity_factor=1.0, distanc
 
 
 def segment_graph(nv, a, b, w, c, tie_order=0):
-    """tie_order 0: equal weights in creation order (the product's default); 1: this C++ runtime's std::sort."""
+    """tie_order 0: equal weights in creation order (the product's device sort); 1: this C++ runtime's std::sort (the product's default)."""
     root = np.zeros(nv, np.int32)
     sets = lib().orc_segment_graph(nv, a.size, np.ascontiguousarray(a, np.int32), np.ascontiguousarray(b, np.int32),
                                    np.ascontiguousarray(w, np.float32), float(c), int(tie_order), root)
