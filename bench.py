@@ -438,6 +438,10 @@ def main():
                     "iterations/chain" % (a.total_frames, len(scenes), cpf, world, a.iters_per_step))
     if n_local <= 0:
         raise SystemExit("bench.py: rank %d has nothing to do (more ranks than units)" % rank)
+    if cfg == "c5" and a.total_frames % world != 0:
+        # the marginal all-gather stacks equal blocks in rank order; an uneven split would need padding
+        print("bench.py: --total-frames %d does not divide over %d ranks" % (a.total_frames, world), file=sys.stderr)
+        raise SystemExit(2)
     W, H = scenes[0].width, scenes[0].height
     smax = max(s.n_superpixels for s in scenes); emax = max(s.col.size for s in scenes)
     sc = scenes[0]
@@ -484,24 +488,24 @@ def main():
     total_steps = (a.warmup + a.steps) * a.iters_per_step
     assert (sca["status"] == 0).all(), "a chain reported an error status"
     assert (sca["n_case"].sum(axis=1) == total_steps).all()
-    best_e, best_chain, best_labels, per_rank = D.gather_best(sca["best_energy"], ctx.labels(1, True), chain_off)
+    # the rank's arg-max is taken on the device (mcmc_chains_get_best): one labeling per rank enters the all-gather,
+    # straight from the library's device memory when the backend is RCCL
+    best_e, best_chain, best_labels, per_rank = D.gather_best_ctx(ctx, which=1, canonical=True)
+    host_e = sca["best_energy"]
+    assert best_e >= float(host_e.max()) and (len(per_rank) > 1 or best_chain == chain_off + int(np.flatnonzero(host_e == host_e.max())[0]))
     if shared:      # every rank sampled the same frame: all-reduce(sum)
-        marg = D.reduce_marginals(ctx.marginals(0), shared_frames=True)
+        marg = D.reduce_marginals_ctx(ctx, 1, shared_frames=True)
         n_valid = int((ctx.local_fit(0)[1] != 0).sum())
         # every valid superpixel is counted once per chain per measured sampler iteration, on every rank
         assert int(marg.sum()) == total_chains * total_steps * n_valid
         frames_gathered = 1
-    else:           # disjoint frames: all-gather, rank blocks in frame order (equal shares required)
-        mine = np.stack([ctx.marginals(f) for f in range(frames_local)])
-        if a.total_frames % world == 0:
-            marg = D.reduce_marginals(mine, shared_frames=False)
-            frames_gathered = int(marg.shape[0])
-            assert frames_gathered == a.total_frames
-            per_frame = marg.reshape(a.total_frames, -1).sum(axis=1)
-            nv = [int((ctx.local_fit(f)[1] != 0).sum()) for f in range(frames_local)]
-            assert all(int(per_frame[first_frame + f]) == cpf * total_steps * nv[f] for f in range(frames_local))
-        else:
-            marg, frames_gathered = mine, frames_local
+    else:           # disjoint frames: all-gather, rank blocks in frame order (equal shares, checked above)
+        marg = D.reduce_marginals_ctx(ctx, frames_local, shared_frames=False)
+        frames_gathered = int(marg.shape[0])
+        assert frames_gathered == a.total_frames
+        per_frame = marg.reshape(a.total_frames, -1).sum(axis=1)
+        nv = [int((ctx.local_fit(f)[1] != 0).sum()) for f in range(frames_local)]
+        assert all(int(per_frame[first_frame + f]) == cpf * total_steps * nv[f] for f in range(frames_local))
     # one chain per rank (its first): the trace hash a single-GPU run gives the same global chain id is
     # recomputed on the oracle in the cpu_baseline leg below
     first = np.array([chain_off, int(sca["trace_hash"][0]) >> 32, int(sca["trace_hash"][0]) & 0xFFFFFFFF], np.int64)

@@ -141,6 +141,20 @@ int mcmc_chains_get_trace(mcmc_ctx *ctx, uint8_t *out /* n_chains*steps of last 
  * (Segmentation.cpp:197-233); else the smallest member id of each segment.
  * which = 2 returns MCMC_E_OVERFLOW (labels still written) if a caller-fixed visit table filled up. */
 int mcmc_chains_get_labels(mcmc_ctx *ctx, int which, int canonical, uint16_t *out /* n_chains*s_max */);
+/* The ONE labeling a caller prints or exchanges (printResults, src/exe/can05_sampler.cpp:23-45 takes
+ * Statistics::getOrderedStates().front(), Statistics.h:50-70; north_star's all-gather of best-energy labelings):
+ * the arg-max over this context's chains is taken on the device -- which = 1: highest best-energy, which = 2: most
+ * visits of a chain's most-visited state; ties go to the lowest chain id -- and only that chain's labeling comes
+ * back (s_max labels, MCMC_NOLABEL beyond the frame's superpixels; canonical as in mcmc_chains_get_labels).
+ * energy / visits: the chosen chain's best energy and top count; chain: its GLOBAL id (chain_offset + k).  Any
+ * output pointer may be NULL.  which = 2 returns MCMC_E_OVERFLOW (outputs still written) if that chain's
+ * caller-fixed visit table filled up. */
+int mcmc_chains_get_best(mcmc_ctx *ctx, int which, int canonical, double *energy, uint64_t *visits,
+                         uint64_t *chain, uint16_t *labels /* s_max */);
+/* The same record left on the device for a collective (RCCL all-gather without a host copy): 8-byte words
+ * [0] the key (which = 1: energy as f64 bits; 2: visit count), [1] global chain id, [2..] the labels, four per
+ * word; *bytes = (2 + (s_max + 3) / 4) * 8.  Valid on the context's stream until the next call of either. */
+int mcmc_chains_best_record_device(mcmc_ctx *ctx, int which, int canonical, const void **d_record, size_t *bytes);
 /* Any pointer may be NULL.  n_case: 3 per chain.  status: per-chain MCMC_E_*. */
 int mcmc_chains_get_scalars(mcmc_ctx *ctx, double *energy, double *best_energy, uint64_t *state_hash,
                             uint64_t *trace_hash, uint64_t *n_accept, uint64_t *n_case,
@@ -161,6 +175,9 @@ int mcmc_chains_reserve_visits(mcmc_ctx *ctx, uint64_t measured_steps);
 int mcmc_chains_get_last_ratios(mcmc_ctx *ctx, double *targetL, double *proposal);
 /* Label marginals of one frame summed over its chains: s_max*marginal_bins counts. */
 int mcmc_frame_get_marginals(mcmc_ctx *ctx, int frame, uint64_t *out);
+/* The same counts where they live (device memory, uint64[s_max * marginal_bins]) for a collective on the device;
+ * read-only for the caller, changed by every mcmc_chains_run. */
+int mcmc_frame_marginals_device(mcmc_ctx *ctx, int frame, const void **d_counts, size_t *count);
 /* Segmentation::computeProbability (Segmentation.cpp:185-195) recomputed from the segment cache. */
 int mcmc_chains_recompute_energy(mcmc_ctx *ctx, double *out /* n_chains */);
 

@@ -50,6 +50,7 @@ struct Chains {
     unsigned long long trace_cap = 0, last_steps = 0;
     unsigned long long* slots_g = nullptr; size_t slots_cap = 0;
     double *last_targetL = nullptr, *last_prop = nullptr;
+    unsigned long long* best_rec = nullptr; // packed record of mcmc_chains_get_best: key, global chain id, labels
     int hcap = 0;                          // slots per chain of the visit table (grows when visit_capacity == 0)
     unsigned long long measured = 0;       // Statistics::update calls made so far per chain (steps after burn-in)
 };
@@ -126,7 +127,7 @@ void free_chains(Chains& h)
     dfree(h.segC); dfree(h.energy); dfree(h.best_energy); dfree(h.tmp_energy);
     dfree(h.state_hash); dfree(h.trace_hash); dfree(h.n_accept); dfree(h.n_case);
     dfree(h.visit_hash); dfree(h.visit_count); dfree(h.overflow); dfree(h.top_count); dfree(h.top_hash);
-    dfree(h.status); dfree(h.trace); dfree(h.slots_g); dfree(h.last_targetL); dfree(h.last_prop);
+    dfree(h.status); dfree(h.trace); dfree(h.slots_g); dfree(h.last_targetL); dfree(h.last_prop); dfree(h.best_rec);
     h = Chains();
 }
 
@@ -611,6 +612,7 @@ int mcmc_chains_init(mcmc_ctx* c, int n_chains, int cpf, uint32_t seed, uint32_t
     HIPCHK(c, dalloc(&h.overflow, N)); HIPCHK(c, dalloc(&h.top_count, N)); HIPCHK(c, dalloc(&h.top_hash, N));
     HIPCHK(c, dalloc(&h.status, N));
     HIPCHK(c, dalloc(&h.last_targetL, N)); HIPCHK(c, dalloc(&h.last_prop, N));
+    HIPCHK(c, dalloc(&h.best_rec, 2 + ((size_t)c->s_max + 3) / 4));
     HIPCHK(c, hipMemsetAsync(c->d_marg, 0, (size_t)c->n_frames * c->s_max * (size_t)c->p.marginal_bins * 8, c->stream));
     ChainArgs a = chain_args(c);
     HIPCHK(c, launch_chain_init(a, c->stream));
@@ -742,6 +744,52 @@ int mcmc_chains_get_labels(mcmc_ctx* c, int which, int canonical, uint16_t* out)
     // written; the status says so (only possible with a caller-fixed visit_capacity).
     for (unsigned long long o : ovf)
         if (o) return fail(c, MCMC_E_OVERFLOW, "chains_get_labels: a chain's visit table overflowed (visit_capacity too small); the most-visited state may be wrong");
+    return MCMC_OK;
+}
+
+// One labeling for the whole job (printResults, can05_sampler.cpp:23-45): arg-max on the device, one record back.
+int mcmc_chains_best_record_device(mcmc_ctx* c, int which, int canonical, const void** d_record, size_t* bytes)
+{
+    if (!c || (which != 1 && which != 2) || !d_record) return fail(c, MCMC_E_BADARG, "chains_best_record_device: bad argument");
+    if (c->ch.n == 0) return fail(c, MCMC_E_STATE, "chains_best_record_device: no chains");
+    HIPCHK(c, hipSetDevice(c->device));
+    ChainArgs a = chain_args(c);
+    HIPCHK(c, launch_best_record(a, which, canonical, c->ch.best_rec, c->stream));
+    *d_record = c->ch.best_rec;
+    if (bytes) *bytes = (2 + ((size_t)c->s_max + 3) / 4) * 8;
+    return MCMC_OK;
+}
+
+int mcmc_chains_get_best(mcmc_ctx* c, int which, int canonical, double* energy, uint64_t* visits, uint64_t* chain, uint16_t* labels)
+{
+    const void* d = nullptr;
+    size_t bytes = 0;
+    const int rc = mcmc_chains_best_record_device(c, which, canonical, &d, &bytes);
+    if (rc != MCMC_OK) return rc;
+    std::vector<unsigned long long> rec(bytes / 8);
+    HIPCHK(c, hipMemcpyAsync(rec.data(), d, bytes, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long ovf = 0ull, cnt = 0ull; double e = 0.0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t local = (size_t)(rec[1] - (unsigned long long)c->ch.offset);
+    // the other figure of the chosen chain, and whether its visit table overflowed (most-visited may then be wrong)
+    HIPCHK(c, hipMemcpyAsync(&e, c->ch.best_energy + local, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->ch.top_count + local, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&ovf, c->ch.overflow + local, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (energy) *energy = e;
+    if (visits) *visits = cnt;
+    if (chain) *chain = rec[1];
+    if (labels) std::memcpy(labels, rec.data() + 2, (size_t)c->s_max * 2);
+    if (which == 2 && ovf) return fail(c, MCMC_E_OVERFLOW, "chains_get_best: the chosen chain's visit table overflowed (visit_capacity too small); the most-visited state may be wrong");
+    return MCMC_OK;
+}
+
+int mcmc_frame_marginals_device(mcmc_ctx* c, int frame, const void** d_counts, size_t* count)
+{
+    if (!frame_ok(c, frame) || !d_counts) return fail(c, MCMC_E_BADARG, "frame_marginals_device: bad argument");
+    const size_t n = (size_t)c->s_max * (size_t)c->p.marginal_bins;
+    *d_counts = c->d_marg + (size_t)frame * n;
+    if (count) *count = n;
     return MCMC_OK;
 }
 

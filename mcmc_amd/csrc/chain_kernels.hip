@@ -1133,6 +1133,76 @@ __global__ __launch_bounds__(64) void canonical_labels_kernel(const uint16_t* sr
     }
 }
 
+// The one labeling a caller prints (printResults, can05_sampler.cpp:23-45; north_star's "best-energy labeling" that the
+// ranks all-gather): arg-max over the chains on the device, ties to the lowest chain id, and that chain's labels, as
+// one packed record rec[0] = the key (which = 1: best energy, f64 bits; which = 2: visits of the most-visited state),
+// rec[1] = global chain id, then the labels, four u16 per word (kNoLabel beyond the frame's superpixels).
+__global__ __launch_bounds__(64) void best_record_kernel(ChainArgs a, int which, int canonical, unsigned long long* rec)
+{
+    extern __shared__ uint32_t sh[];  // rbits[NW] | rpre[NW]
+    const int lane = lane_id();
+    int besti = 0x7FFFFFFF;
+    double bestv = 0.0;
+    unsigned long long bestc = 0ull;
+    for (int k = lane; k < a.n_chains; k += kWave) {
+        if (which == 1) {
+            const double v = a.best_energy[k];
+            if (besti == 0x7FFFFFFF ? v == v : v > bestv) { bestv = v; besti = k; }   // NaN never wins
+        } else {
+            const unsigned long long c = a.top_count[k];
+            if (besti == 0x7FFFFFFF || c > bestc) { bestc = c; besti = k; }
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int oi = __shfl_xor(besti, off, kWave);
+        const double ov = __shfl_xor(bestv, off, kWave);
+        const unsigned long long oc = __shfl_xor(bestc, off, kWave);
+        bool take;
+        if (oi == 0x7FFFFFFF) take = false;
+        else if (besti == 0x7FFFFFFF) take = true;
+        else if (which == 1) take = ov > bestv || (ov == bestv && oi < besti);
+        else take = oc > bestc || (oc == bestc && oi < besti);
+        if (take) { besti = oi; bestv = ov; bestc = oc; }
+    }
+    if (besti == 0x7FFFFFFF) { besti = 0; bestv = a.best_energy[0]; bestc = a.top_count[0]; }   // every energy NaN
+    const int chain = besti;
+    const int S = a.S[chain / a.chains_per_frame];
+    const uint16_t* lab = (which == 1 ? a.best_label : a.top_label) + (size_t)chain * a.s_max;
+    uint16_t* out = reinterpret_cast<uint16_t*>(rec + 2);
+    const int NW = (a.s_max + 63) / 64 * 2;
+    uint32_t* rbits = sh;
+    uint32_t* rpre = sh + NW;
+    if (canonical) {
+        uint32_t running = 0;
+        for (int b = 0; b < S; b += kWave) {
+            const int i = b + lane;
+            const bool root = i < S && lab[i] == (uint16_t)i;
+            const uint64_t m = __ballot(root);
+            if (lane == 0) {
+                rbits[b >> 5] = (uint32_t)m; rpre[b >> 5] = running;
+                rbits[(b >> 5) + 1] = (uint32_t)(m >> 32); rpre[(b >> 5) + 1] = running + (uint32_t)__popc((uint32_t)m);
+            }
+            running += (uint32_t)__popcll((unsigned long long)m);
+        }
+        __syncthreads();
+    }
+    const int padded = (a.s_max + 3) & ~3;
+    for (int i = lane; i < padded; i += kWave) {
+        uint16_t o = kNoLabel;
+        if (i < S) {
+            const uint32_t Lb = lab[i];
+            if (Lb != kNoLabel)
+                o = canonical ? (uint16_t)(rpre[Lb >> 5] + (uint32_t)__popc(rbits[Lb >> 5] & ((1u << (Lb & 31u)) - 1u))) : (uint16_t)Lb;
+        }
+        out[i] = o;
+    }
+    if (lane == 0) {
+        rec[0] = which == 1 ? (unsigned long long)d2u(bestv) : bestc;
+        rec[1] = (unsigned long long)a.chain_offset + (unsigned long long)chain;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1236,6 +1306,13 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
         }
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_best_record(const ChainArgs& a, int which, int canonical, unsigned long long* rec, hipStream_t st)
+{
+    const int NW = (a.s_max + 63) / 64 * 2;
+    hipLaunchKernelGGL(best_record_kernel, dim3(1), dim3(64), (size_t)NW * 8, st, a, which, canonical, rec);
+    return hipGetLastError();
 }
 
 hipError_t launch_visit_rehash(const unsigned long long* oh, const unsigned long long* oc, int ocap, unsigned long long* nh,

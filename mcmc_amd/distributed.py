@@ -61,6 +61,28 @@ def local_best(best_energy: np.ndarray, best_labels: np.ndarray, chain_offset: i
     return float(e[k]), np.uint64(chain_offset + k), np.ascontiguousarray(best_labels[k], np.uint16)
 
 
+def pack_best(e, cid, lab):
+    """One packed int64 record: energy bits, global chain id, labels (4 per word) -- the layout of
+    mcmc_chains_best_record_device."""
+    S = lab.size
+    rec = np.zeros(2 + (S + 3) // 4, np.int64)
+    rec[0] = np.float64(e).view(np.int64)
+    rec[1] = np.uint64(cid).astype(np.uint64).view(np.int64)
+    padded = np.full(((S + 3) // 4) * 4, 0xFFFF, np.uint16)
+    padded[:S] = lab
+    rec[2:] = padded.view(np.int64)
+    return rec
+
+
+def _pick_best(allrec, S):
+    es = allrec[:, 0].copy().view(np.float64)
+    cids = allrec[:, 1].copy().view(np.uint64)
+    order = np.lexsort((cids, -es))       # highest energy, then lowest chain id
+    w = int(order[0])
+    labels = allrec[w, 2:].copy().view(np.uint16)[:S]
+    return float(es[w]), int(cids[w]), labels, [(float(a), int(b)) for a, b in zip(es, cids)]
+
+
 def gather_best(best_energy, best_labels, chain_offset):
     """All-gather every rank's best labeling; returns (energy, global chain id,
     labels, per_rank) where per_rank lists every rank's (energy, chain id)."""
@@ -71,25 +93,71 @@ def gather_best(best_energy, best_labels, chain_offset):
         return e, int(cid), lab, [(e, int(cid))]
     dev = _device()
     world = dist.get_world_size()
-    S = lab.size
-    # one packed int64 record per rank: energy bits, chain id, labels (4 per word)
-    nw = 2 + (S + 3) // 4
-    rec = np.zeros(nw, np.int64)
-    rec[0] = np.float64(e).view(np.int64)
-    rec[1] = np.uint64(cid).astype(np.uint64).view(np.int64)
-    padded = np.zeros(((S + 3) // 4) * 4, np.uint16)
-    padded[:S] = lab
-    rec[2:] = padded.view(np.int64)
-    mine = torch.from_numpy(rec).to(dev)
-    out = torch.empty(world * nw, dtype=torch.int64, device=dev)
+    rec = pack_best(e, cid, lab)
+    out = torch.empty(world * rec.size, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, torch.from_numpy(rec).to(dev))
+    return _pick_best(out.cpu().numpy().reshape(world, rec.size), lab.size)
+
+
+class _DeviceMemory:
+    """A span of device memory owned by the C library, as torch sees it (no copy)."""
+
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr, n_words):
+    """int64 torch tensor over `n_words` 8-byte words of the library's device memory at `ptr`."""
+    import torch
+    return torch.as_tensor(_DeviceMemory(ptr, n_words), device=torch.device("cuda", torch.cuda.current_device()))
+
+
+def gather_best_ctx(ctx, which=1, canonical=True):
+    """gather_best for a mcmc_amd.host.Context: the arg-max over the rank's chains is taken on the device
+    (mcmc_chains_get_best) and, over RCCL, the packed record goes from the library's device memory into the
+    all-gather as it is -- one labeling per rank crosses the links, none crosses the host bus before the result."""
+    dist = _dist()
+    S = ctx.s_max
+    if dist is None or dist.get_backend() != "nccl":
+        e, _, cid, lab = ctx.best(which, canonical)
+        if dist is None:
+            return e, cid, lab, [(e, cid)]
+        import torch
+        world = dist.get_world_size()
+        rec = pack_best(e, cid, lab)
+        out = torch.empty(world * rec.size, dtype=torch.int64)
+        dist.all_gather_into_tensor(out, torch.from_numpy(rec))
+        return _pick_best(out.numpy().reshape(world, rec.size), S)
+    import torch
+    ptr, nbytes = ctx.best_record_device(which, canonical)
+    ctx.synchronize()                      # the record is written on the context's stream
+    mine = device_view(ptr, nbytes // 8)
+    world = dist.get_world_size()
+    out = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
     dist.all_gather_into_tensor(out, mine)
-    allrec = out.cpu().numpy().reshape(world, nw)
-    es = allrec[:, 0].copy().view(np.float64)
-    cids = allrec[:, 1].copy().view(np.uint64)
-    order = np.lexsort((cids, -es))       # highest energy, then lowest chain id
-    w = int(order[0])
-    labels = allrec[w, 2:].copy().view(np.uint16)[:S]
-    return float(es[w]), int(cids[w]), labels, [(float(a), int(b)) for a, b in zip(es, cids)]
+    return _pick_best(out.cpu().numpy().reshape(world, mine.numel()), S)
+
+
+def reduce_marginals_ctx(ctx, n_frames, shared_frames=True):
+    """reduce_marginals for a Context's frames [0, n_frames): over RCCL the counts are read where the library keeps
+    them (device memory), summed / gathered on the device, and only the result is copied to the host."""
+    dist = _dist()
+    if dist is None or dist.get_backend() != "nccl":
+        m = np.stack([ctx.marginals(f) for f in range(n_frames)])
+        return reduce_marginals(m[0] if shared_frames and n_frames == 1 else m, shared_frames)
+    import torch
+    ptr, per_frame = ctx.marginals_device(0)
+    ctx.synchronize()
+    shape = (n_frames, ctx.s_max, per_frame // ctx.s_max)
+    t = device_view(ptr, n_frames * per_frame).clone()      # the library's counts stay as they are
+    if shared_frames:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out = t.cpu().numpy().view(np.uint64).reshape(shape)
+        return out[0] if n_frames == 1 else out
+    world = dist.get_world_size()
+    out = torch.empty(world * t.numel(), dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy().view(np.uint64).reshape((world * n_frames,) + shape[1:])
 
 
 def reduce_marginals(marg: np.ndarray, shared_frames: bool = True) -> np.ndarray:

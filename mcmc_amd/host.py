@@ -88,6 +88,9 @@ def load():
         "mcmc_chains_get_trace": (i, [vp, vp]),
         "mcmc_chains_get_labels": (i, [vp, i, i, vp]),
         "mcmc_chains_get_scalars": (i, [vp] + [vp] * 10),
+        "mcmc_chains_get_best": (i, [vp, i, i, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64), vp]),
+        "mcmc_chains_best_record_device": (i, [vp, i, i, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "mcmc_frame_marginals_device": (i, [vp, i, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "mcmc_chains_get_visits": (i, [vp, vp, vp]),
         "mcmc_chains_visit_capacity": (i, [vp]),
         "mcmc_chains_reserve_visits": (i, [vp, u64]),
@@ -279,6 +282,27 @@ class Context:
                  overflow=np.zeros(n, np.uint64))
         self._ck(self.L.mcmc_chains_get_scalars(self.h, *[v.ctypes.data_as(C.c_void_p) for v in d.values()]))
         return d
+
+    def best(self, which=1, canonical=True):
+        """The one labeling of the job (arg-max on the device; which = 1 best energy, 2 most visited):
+        (energy, visits, global chain id, labels[s_max])."""
+        e = C.c_double(); v = C.c_uint64(); k = C.c_uint64()
+        lab = np.zeros(self.s_max, np.uint16)
+        self._ck(self.L.mcmc_chains_get_best(self.h, which, int(canonical), C.byref(e), C.byref(v), C.byref(k),
+                                             _ptr(lab, np.uint16)))
+        return e.value, int(v.value), int(k.value), lab
+
+    def best_record_device(self, which=1, canonical=True):
+        """(device pointer, bytes) of the packed record [key, global chain id, labels] for a collective."""
+        d = C.c_void_p(); n = C.c_size_t()
+        self._ck(self.L.mcmc_chains_best_record_device(self.h, which, int(canonical), C.byref(d), C.byref(n)))
+        return d.value, int(n.value)
+
+    def marginals_device(self, frame):
+        """(device pointer, count) of the frame's uint64 label-marginal counts."""
+        d = C.c_void_p(); n = C.c_size_t()
+        self._ck(self.L.mcmc_frame_marginals_device(self.h, frame, C.byref(d), C.byref(n)))
+        return d.value, int(n.value)
 
     def visit_capacity(self):
         return int(self.L.mcmc_chains_visit_capacity(self.h))

@@ -64,3 +64,38 @@ def test_parent_relays_rank0_line_and_exit_code(tmp_path):
     assert "noise from a rank" in ok.stderr
     bad = subprocess.run([sys.executable, "-c", run, "7"], capture_output=True, text=True)
     assert bad.returncode == 7 and bad.stdout.strip() == ""
+
+
+def _run_bench(args, env_extra):
+    env = dict(os.environ); env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["c3", "c5"])
+def test_sharded_configs_through_rccl_one_rank(cfg):
+    """The multi-GPU modes of bench.py at reduced size with the process group really initialised (backend nccl =
+    RCCL, one rank: this box has one GPU): chains / frames are placed by shard_range, the best labeling and the
+    marginals go through the collectives from device memory, and the first chain is re-run on the oracle."""
+    port = 29600 + (os.getpid() % 300) + (0 if cfg == "c3" else 1)
+    args = ["--config", cfg, "--steps", "1", "--warmup", "1", "--iters-per-step", "60", "--no-roofline", "--cpu-seconds", "1"]
+    args += ["--total-chains", "64"] if cfg == "c3" else ["--total-frames", "8", "--chains-per-frame", "16", "--distinct-scenes", "2"]
+    out = _run_bench(args, {"MCMC_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                            "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    c = out["config"]
+    assert out["n_gpus"] == 1 and c["name"] == cfg and c["ranks_gathered"] == 1
+    assert out["scaling"] == "strong" and out["value"] > 0
+    assert c["chains_total"] == (64 if cfg == "c3" else 8 * 16)
+    assert c["marginal_frames_gathered"] == (1 if cfg == "c3" else 8)
+    assert out["cpu_baseline"]["same_computation"]["identical_to_gpu"] is True
+    assert out["statistics"]["overflow_sum"] == 0
+
+
+def test_c5_refuses_uneven_frame_shares():
+    a = bench.parse(["--gpus", "3", "--config", "c5", "--total-frames", "8"])
+    assert a.total_frames % 3 != 0      # main() exits 2 before any work; the check itself needs ranks, see bench.py

@@ -93,7 +93,7 @@ def test_two_rank_gloo_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in procs])
+    res = sorted([q.get(timeout=90) for _ in procs])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -124,3 +124,95 @@ def test_two_rank_gloo_matches_single_process():
     assert res[0][8] == tot and res[1][8] == tot
     for r in res:
         assert r[9] == [[0, 1], [3, 11]] and r[10] == [6, 6]
+
+
+def _worker_frames(rank, world, port, q):
+    """C5 shape: the FRAMES are sharded (two per rank, three chains each); marginals are all-gathered in frame order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mcmc_amd.scene import make_scene
+        from tests import oracle_lib as O
+        total_frames, cpf = 2 * world, 3
+        f_off, f_cnt = D.shard_range(total_frames, world, rank)
+        margs, best_e, best_l, hashes = [], [], [], []
+        smax = 0
+        for f in range(f_off, f_off + f_cnt):
+            sc = make_scene(width=160, height=120, n_planes=3, n_superpixels=36, seed=200 + f)
+            S = sc.n_superpixels
+            smax = max(smax, S)
+            fit, valid, _ = O.local_fit(O.moments(sc.disp, sc.label, S), sc.width, sc.height)
+            _, qe = O.edge_probs(fit, valid, sc.row_ptr, sc.col)
+            ch = O.Chains(fit, valid, sc.row_ptr, sc.col, qe, cpf, seed=5, chain_offset=f * cpf)
+            ch.run(20, 60)
+            m = np.zeros((64, 64), np.uint64); m[:S] = ch.marginals()          # frames padded to one s_max, as the library does
+            margs.append(m)
+            lab = np.full((cpf, 64), 0xFFFF, np.uint16); lab[:, :S] = ch.labels(1, True)
+            best_e.append(ch.scalars()["best_energy"]); best_l.append(lab)
+            hashes += ch.scalars()["trace_hash"].tolist()
+        cat = D.reduce_marginals(np.stack(margs), shared_frames=False)
+        be, cid, bl, per = D.gather_best(np.concatenate(best_e), np.concatenate(best_l), f_off * cpf)
+        q.put((rank, cat.tolist(), be, cid, bl.tolist(), hashes, per))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_frame_sharding_matches_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_frames, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=90) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # the same job on one rank (no process group: the single-process paths)
+    q1 = ctx.Queue()
+    port1 = _free_port()
+    p1 = ctx.Process(target=_worker_frames_single, args=(port1, q1))
+    p1.start()
+    one = q1.get(timeout=180)
+    p1.join(60)
+    assert p1.exitcode == 0
+    for r in res:
+        assert r[1] == one[1]                       # gathered marginals: rank blocks in frame order = all four frames
+        assert (r[2], r[3], r[4]) == (one[2], one[3], one[4])   # same global best on both ranks and on one rank
+        assert len(r[6]) == 2
+    assert res[0][5] + res[1][5] == one[5]          # the chains of a frame do not depend on who owns the frame
+
+
+def _worker_frames_single(port, q):
+    # world of one rank, still through the collectives (gloo)
+    _worker_frames_as(0, 1, port, q, total_world=2)
+
+
+def _worker_frames_as(rank, world, port, q, total_world):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mcmc_amd.scene import make_scene
+        from tests import oracle_lib as O
+        total_frames, cpf = 2 * total_world, 3
+        margs, best_e, best_l, hashes = [], [], [], []
+        for f in range(total_frames):
+            sc = make_scene(width=160, height=120, n_planes=3, n_superpixels=36, seed=200 + f)
+            S = sc.n_superpixels
+            fit, valid, _ = O.local_fit(O.moments(sc.disp, sc.label, S), sc.width, sc.height)
+            _, qe = O.edge_probs(fit, valid, sc.row_ptr, sc.col)
+            ch = O.Chains(fit, valid, sc.row_ptr, sc.col, qe, cpf, seed=5, chain_offset=f * cpf)
+            ch.run(20, 60)
+            m = np.zeros((64, 64), np.uint64); m[:S] = ch.marginals()
+            margs.append(m)
+            lab = np.full((cpf, 64), 0xFFFF, np.uint16); lab[:, :S] = ch.labels(1, True)
+            best_e.append(ch.scalars()["best_energy"]); best_l.append(lab)
+            hashes += ch.scalars()["trace_hash"].tolist()
+        cat = D.reduce_marginals(np.stack(margs), shared_frames=False)
+        be, cid, bl, per = D.gather_best(np.concatenate(best_e), np.concatenate(best_l), 0)
+        q.put((rank, cat.tolist(), be, cid, bl.tolist(), hashes, per))
+    finally:
+        dist.destroy_process_group()

@@ -266,6 +266,40 @@ def test_chain_parity_speculative_form_long_run(gpu_ctx_factory):
                               plain[k].view(np.uint64) if plain[k].dtype == np.float64 else plain[k]), k
 
 
+def test_best_labeling_on_the_device(scene_c2_small, gpu_ctx_factory):
+    # mcmc_chains_get_best: the arg-max over the chains on the device (ties to the lowest chain id) and one labeling
+    # back, against the arg-max taken on the host over every chain's read-back, and against the oracle's chain
+    sc = scene_c2_small
+    S = sc.n_superpixels
+    ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
+    ctx.frames_alloc(1, S + 3, sc.col.size)                   # s_max above S: the padding reads MCMC_NOLABEL
+    _load(ctx, 0, sc)
+    ctx.frames_moments(); ctx.frames_edge_probs()
+    n, off = 70, 1000
+    ctx.chains_init(n, seed=6, chain_offset=off)
+    for burn, iters in ((0, 3), (40, 200)):                  # after 3 steps many chains tie: the lowest id wins
+        ctx.chains_run(burn, iters)
+        s = ctx.scalars()
+        for which, key, lab_which in ((1, s["best_energy"], 1), (2, s["top_count"], 2)):
+            k = int(np.flatnonzero(key == key.max())[0])
+            for canon in (True, False):
+                e, v, cid, lab = ctx.best(which, canon)
+                assert cid == off + k, (which, cid, k)
+                assert bits(e) == bits(s["best_energy"][k]) and v == int(s["top_count"][k])
+                want = ctx.labels(lab_which, canon)[k]
+                assert np.array_equal(lab, want) and (lab[S:] == 0xFFFF).all()
+    orc = _oracle_chains(sc, n, seed=6, off=off)
+    orc.run(0, 3); orc.run(40, 200)
+    e, v, cid, lab = ctx.best(1, True)
+    oe = orc.scalars()["best_energy"]
+    assert bits(e) == bits(oe.max()) and np.array_equal(lab[:S], orc.labels(1, True)[cid - off])
+    # the record a collective reads is the same data, on the device
+    import ctypes
+    ptr, nbytes = ctx.best_record_device(1, True)
+    ctx.synchronize()
+    assert nbytes == (2 + (S + 3 + 3) // 4) * 8 and ptr
+
+
 def test_chain_offset_sharding(scene_c2_small, gpu_ctx_factory):
     # a shard that owns chains [6, 10) of a 10-chain job reproduces them exactly (multi-GPU rule)
     sc = scene_c2_small
