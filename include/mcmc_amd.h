@@ -51,9 +51,12 @@ typedef struct mcmc_params {
     double disparity_variance;   /* kDisparityVariance = 7 */
     double new_segment_prob;     /* newSegmentProb = 0.8 */
     int32_t marginal_bins;       /* Lmax of the label-marginal histogram (build's choice, 64) */
-    int32_t visit_capacity;      /* Statistics::entries_ (Statistics.h:30): 0 = sized from the run, every visited
-                                  * state is kept, as in the reference (default); > 0 = fixed number of slots per
-                                  * chain, visits of further states are counted in `overflow` */
+    int32_t visit_capacity;      /* Statistics::entries_ (Statistics.h:30): 0 = grows with the run so that every
+                                  * visited state is kept, as in the reference (default: starts at 512 slots per
+                                  * chain and grows from the MEASURED occupancy -- slots in use + steps about to be
+                                  * made, not twice the steps ever made; if the larger table cannot be allocated the
+                                  * run goes on and further states count as `overflow`); > 0 = fixed number of
+                                  * slots per chain, visits of further states are counted in `overflow` */
 } mcmc_params;
 
 void mcmc_default_params(mcmc_params *p);
@@ -167,7 +170,8 @@ int mcmc_chains_get_visits(mcmc_ctx *ctx, uint64_t *hash, uint64_t *count);
 /* Slots per chain of the visit table right now (it grows with the run when params.visit_capacity == 0). */
 int mcmc_chains_visit_capacity(const mcmc_ctx *ctx);
 /* Optional: make room now for `measured_steps` further Statistics::update calls per chain, so that no later
- * mcmc_chains_run has to grow the table (growing allocates and re-inserts). */
+ * mcmc_chains_run has to look at the table or grow it (looking synchronises the stream; growing allocates and
+ * re-inserts). */
 int mcmc_chains_reserve_visits(mcmc_ctx *ctx, uint64_t measured_steps);
 /* The out-parameters of Problem::propose for the last step each chain took (Problem.cpp:116,213-217;
  * MCMC.h:214-219): targetRatio (log domain, the literal 1.0 of case A included) and proposalRatio (linear).

@@ -53,9 +53,11 @@ struct Chains {
     unsigned long long* best_rec = nullptr; // packed record of mcmc_chains_get_best: key, global chain id, labels
     int hcap = 0;                          // slots per chain of the visit table (grows when visit_capacity == 0)
     unsigned long long measured = 0;       // Statistics::update calls made so far per chain (steps after burn-in)
+    unsigned long long occ_known = 0, since_known = 0;   // largest table occupancy when last read; measured steps since
+    unsigned int* d_occ = nullptr;
 };
 
-constexpr int kVisitCapAuto0 = 256;        // first size of an automatically sized visit table
+constexpr int kVisitCapAuto0 = 512;        // first size of an automatically sized visit table
 constexpr int kVisitCapMax = 1 << 22;      // 4 Mi slots (64 MB) per chain: beyond this visits count as overflow
 
 }  // namespace
@@ -127,7 +129,7 @@ void free_chains(Chains& h)
     dfree(h.segC); dfree(h.energy); dfree(h.best_energy); dfree(h.tmp_energy);
     dfree(h.state_hash); dfree(h.trace_hash); dfree(h.n_accept); dfree(h.n_case);
     dfree(h.visit_hash); dfree(h.visit_count); dfree(h.overflow); dfree(h.top_count); dfree(h.top_hash);
-    dfree(h.status); dfree(h.trace); dfree(h.slots_g); dfree(h.last_targetL); dfree(h.last_prop); dfree(h.best_rec);
+    dfree(h.status); dfree(h.trace); dfree(h.slots_g); dfree(h.last_targetL); dfree(h.last_prop); dfree(h.best_rec); dfree(h.d_occ);
     h = Chains();
 }
 
@@ -167,26 +169,52 @@ ChainArgs chain_args(mcmc_ctx* c)
     return a;
 }
 
-// Statistics keeps every visited state (Statistics.h:30-47).  With visit_capacity == 0 the per-chain table is
-// sized from the run: room for twice the Statistics::update calls made so far plus those about to be made (a
-// chain visits at most one new state per step), so it never fills.  Growing re-inserts the old entries.
-int ensure_visit_capacity(mcmc_ctx* c, unsigned long long measured_total)
+// Statistics keeps every visited state (Statistics.h:30-47).  With visit_capacity == 0 the per-chain table grows
+// with the run so that it never fills: a chain meets at most one new state per measured step, so a table with
+// `occupied + steps about to be made` slots (and a quarter of slack for the probing) cannot overflow.  `occupied` is
+// measured, not assumed: when the worst case since the last look would no longer fit, the real occupancy is read
+// from the device (a chain visits ~1.5 new states per 100 steps at BASELINE config 2), and the table only grows --
+// doubling, re-inserting the old entries -- when that does not fit either.  If the larger table cannot be had
+// (memory, or the 4 Mi-slot limit), the run goes on with the old one and visits of further states are counted in
+// `overflow`, as with a caller-fixed capacity.
+int ensure_visit_capacity(mcmc_ctx* c, unsigned long long steps_next)
 {
     Chains& h = c->ch;
     if (c->p.visit_capacity > 0) return MCMC_OK;          // fixed by the caller: overflow is counted, not avoided
-    unsigned long long want = 2ull * (measured_total + 1ull);
+    auto fits = [&](unsigned long long occupied) {
+        const unsigned long long need = occupied + steps_next;
+        return need + need / 4 <= (unsigned long long)h.hcap;
+    };
+    if (fits(h.occ_known + h.since_known)) return MCMC_OK;
+    // look before growing
+    if (!h.d_occ) HIPCHK(c, dalloc(&h.d_occ, 1));
+    unsigned int occ = 0;
+    HIPCHK(c, hipMemsetAsync(h.d_occ, 0, sizeof(unsigned int), c->stream));
+    HIPCHK(c, launch_visit_occupancy(h.visit_count, h.hcap, h.n, h.d_occ, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&occ, h.d_occ, sizeof occ, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    h.occ_known = occ; h.since_known = 0;
+    if (fits(occ)) return MCMC_OK;
+    unsigned long long want = (unsigned long long)occ + steps_next;
+    want += want / 4;
     if (want > (unsigned long long)kVisitCapMax) want = (unsigned long long)kVisitCapMax;
-    if ((unsigned long long)h.hcap >= want) return MCMC_OK;
+    if ((unsigned long long)h.hcap >= want) return MCMC_OK;   // at the limit: overflow is counted from here on
     int ncap = h.hcap;
     while ((unsigned long long)ncap < want) ncap *= 2;
     const size_t NH = (size_t)h.n * (size_t)ncap;
     unsigned long long *nh = nullptr, *nc = nullptr;
-    HIPCHK(c, dalloc(&nh, NH));
-    if (dalloc(&nc, NH) != hipSuccess) { dfree(nh); return fail(c, MCMC_E_DEVICE, "visit table: out of device memory"); }
-    HIPCHK(c, hipMemsetAsync(nc, 0, NH * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(nh, 0, NH * 8, c->stream));
-    HIPCHK(c, launch_visit_rehash(h.visit_hash, h.visit_count, h.hcap, nh, nc, ncap, h.n, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dalloc(&nh, NH) != hipSuccess || dalloc(&nc, NH) != hipSuccess) {
+        dfree(nh); dfree(nc);
+        (void)hipGetLastError();                          // the failed allocation is not this call's error
+        c->err = "visit table: no device memory for " + std::to_string(ncap) + " slots per chain; states beyond the present "
+                 "table are counted in `overflow`";
+        return MCMC_OK;
+    }
+    hipError_t e = hipMemsetAsync(nc, 0, NH * 8, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(nh, 0, NH * 8, c->stream);
+    if (e == hipSuccess) e = launch_visit_rehash(h.visit_hash, h.visit_count, h.hcap, nh, nc, ncap, h.n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { dfree(nh); dfree(nc); return fail(c, MCMC_E_DEVICE, std::string("visit table growth: ") + hipGetErrorString(e)); }
     dfree(h.visit_hash); dfree(h.visit_count);
     h.visit_hash = nh; h.visit_count = nc; h.hcap = ncap;
     return MCMC_OK;
@@ -642,7 +670,7 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
     if (!c || c->ch.n == 0) return fail(c, MCMC_E_STATE, "chains_run: chains_init first");
     HIPCHK(c, hipSetDevice(c->device));
     Chains& h = c->ch;
-    { const int rc = ensure_visit_capacity(c, h.measured + iters); if (rc != MCMC_OK) return rc; }
+    { const int rc = ensure_visit_capacity(c, iters); if (rc != MCMC_OK) return rc; }
     ChainArgs a = chain_args(c);
     a.step0 = h.step; a.burn_in = burn_in; a.iters = iters;
     const unsigned long long total = burn_in + iters;
@@ -672,7 +700,7 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
         if (e == hipErrorInvalidValue) return fail(c, MCMC_E_TOO_LARGE, "chains_run: per-chain state does not fit 160 KB of LDS");
         HIPCHK(c, e);
     }
-    h.step += total; h.last_steps = total; h.measured += iters;
+    h.step += total; h.last_steps = total; h.measured += iters; h.since_known += iters;
     return MCMC_OK;
 }
 
@@ -680,7 +708,7 @@ int mcmc_chains_reserve_visits(mcmc_ctx* c, uint64_t measured_steps)
 {
     if (!c || c->ch.n == 0) return fail(c, MCMC_E_STATE, "chains_reserve_visits: chains_init first");
     HIPCHK(c, hipSetDevice(c->device));
-    return ensure_visit_capacity(c, c->ch.measured + measured_steps);
+    return ensure_visit_capacity(c, measured_steps);
 }
 
 int mcmc_chains_visit_capacity(const mcmc_ctx* c)

@@ -1080,6 +1080,17 @@ __global__ __launch_bounds__(64) void visit_rehash_kernel(const unsigned long lo
     }
 }
 
+// Largest number of occupied slots over the chains' visit tables (what decides whether a table must grow).
+__global__ __launch_bounds__(64) void visit_occupancy_kernel(const unsigned long long* vc, int hcap, unsigned int* out_max)
+{
+    const int lane = lane_id();
+    vc += (size_t)blockIdx.x * hcap;
+    int n = 0;
+    for (int i = lane; i < hcap; i += kWave) n += vc[i] != 0ull;
+    n = wave_sum_i32(n);
+    if (lane == 0) atomicMax(out_max, (unsigned int)n);
+}
+
 // Segmentation::computeProbability (Segmentation.cpp:185-195): sum of the cached
 // segment log-probabilities, wave order over roots by id.
 __global__ __launch_bounds__(64) void chain_energy_kernel(ChainArgs a, double* out)
@@ -1319,6 +1330,12 @@ hipError_t launch_visit_rehash(const unsigned long long* oh, const unsigned long
                                unsigned long long* nc, int ncap, int n_chains, hipStream_t st)
 {
     hipLaunchKernelGGL(visit_rehash_kernel, dim3(n_chains), dim3(64), 0, st, oh, oc, ocap, nh, nc, ncap);
+    return hipGetLastError();
+}
+
+hipError_t launch_visit_occupancy(const unsigned long long* vc, int hcap, int n_chains, unsigned int* out_max, hipStream_t st)
+{
+    hipLaunchKernelGGL(visit_occupancy_kernel, dim3(n_chains), dim3(64), 0, st, vc, hcap, out_max);
     return hipGetLastError();
 }
 

@@ -113,6 +113,7 @@ hipError_t launch_visit_rehash(const unsigned long long* oh, const unsigned long
                                unsigned long long* nc, int ncap, int n_chains, hipStream_t st);
 // rec: 2 + (s_max + 3) / 4 words -- key, global chain id, labels (four u16 per word)
 hipError_t launch_best_record(const ChainArgs& a, int which, int canonical, unsigned long long* rec, hipStream_t st);
+hipError_t launch_visit_occupancy(const unsigned long long* vc, int hcap, int n_chains, unsigned int* out_max, hipStream_t st);  // *out_max zeroed by the caller
 hipError_t launch_canonical_labels(const uint16_t* src, const uint8_t* valid, const int* S, int s_max,
                                    int n_chains, int chains_per_frame, uint16_t* dst, hipStream_t st);
 
