@@ -193,14 +193,16 @@ double mcmc_last_kernel_ms(mcmc_ctx *ctx, int kernel);
 int mcmc_set_timing(mcmc_ctx *ctx, int enable);
 /* Launch-shape overrides for tuning runs (0 / -1 = automatic): "k1_bands",
  * "k1_threads", "k1_use_lds", "k1_debug", "k3_profile", "k3_dense" (eight chains per workgroup with the records
- * read through L2: -1 never, 0 when the chains exceed four per CU, 1 always), "k3_spec" (two waves per chain, the
- * second evaluating the next step against the undecided state: -1 never, 1 whenever its state fits LDS, 0 = when
- * it fits and there are at most four chains per CU).  Results never depend on them. */
+ * read through L2: -1 never, 0 when the chains exceed four per CU, 1 always), "k3_spec" (several waves per chain in
+ * step order, the further ones evaluating the next steps against the undecided state: -1 never, 0 = as many as fit
+ * LDS, up to three, when there are at most four chains per CU, 1 = the same whatever the chain count, 2..4 = exactly
+ * that many if they fit).  Results never depend on them. */
 int mcmc_ctx_set_option(mcmc_ctx *ctx, const char *name, int value);
 /* Diagnostic (no counterpart in the reference): which form of the chain kernel the last mcmc_chains_run
  * launched, as 10 * placement + chains per workgroup; placement 1 = all frame tables in LDS, 2 = tables in LDS
  * except the per-superpixel records (eight chains per workgroup), 3 = only the CSR topology in LDS (large frames),
- * 4 = the two-wave form (44), 0 = everything behind L2.  Results never depend on it. */
+ * 4 = the speculative form (44 with two waves per chain, 144 with three, 244 with four), 0 = everything behind
+ * L2.  Results never depend on it. */
 int mcmc_chains_last_variant(const mcmc_ctx *ctx);
 
 /* After option "k3_profile" = 1 and a run: shader-clock cycles summed over chains for 12

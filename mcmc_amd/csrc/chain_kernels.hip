@@ -29,6 +29,7 @@
 namespace mc {
 
 constexpr int kLdsLimit = 160 * 1024;
+constexpr int kSpecAuto = 3;    // waves per chain the speculative form takes by itself when they fit (up to 4 on request)
 
 MC_D size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -40,7 +41,7 @@ constexpr uint32_t kTrialPos0 = 8u;
 struct Rng {
     uint32_t k0, k1, step_lo, step_hi;
     int batch;
-    double* buf;                  // LDS, [4][64]: the batch's draws as rand()/RAND_MAX, inclusive of 1 (MCMC.h:223)
+    uint32_t* buf;                // LDS, [4][64]: the batch's raw 32-bit draws (1 KB; a draw becomes rand()/RAND_MAX at its use)
     // the 10 round keys of the chain, pinned in vector registers: they are wave-uniform and loop-invariant, so the
     // compiler would keep all 20 in SGPRs, run out, and park them in lanes of a spill VGPR -- a v_readlane and a
     // hazard nop per round inside the growth loop.  From a VGPR the round's v_xor takes them as they are.
@@ -80,9 +81,7 @@ MC_D u32x4 rng_gen(Rng& g, int batch, int lane)
     u32x4 c = { g.step_lo, g.step_hi, (uint32_t)(batch * 64 + lane), kPhiloxTag };
     u32x4 r = philox_pinned(c, g);
     wave_fence();
-    // the divisions are done once per 256 positions, off the BFS critical path
-    g.buf[lane] = to_unit(r.x); g.buf[64 + lane] = to_unit(r.y);
-    g.buf[128 + lane] = to_unit(r.z); g.buf[192 + lane] = to_unit(r.w);
+    g.buf[lane] = r.x; g.buf[64 + lane] = r.y; g.buf[128 + lane] = r.z; g.buf[192 + lane] = r.w;
     wave_fence();
     g.batch = batch;
     return r;
@@ -90,16 +89,16 @@ MC_D u32x4 rng_gen(Rng& g, int batch, int lane)
 
 // Uniforms of positions p0 + lane, lane < count (p0, count wave-uniform): position p sits at
 // buf[(p >> 6) & 3][p & 63] of its batch.
-MC_D double rng_trial(Rng& g, uint32_t p0, uint32_t count, int lane)
+MC_D uint32_t rng_trial(Rng& g, uint32_t p0, uint32_t count, int lane)
 {
     const uint32_t p = p0 + (uint32_t)lane;
     const uint32_t slot = p & 255u;
     const int b0 = (int)(p0 >> 8);
     if (b0 != g.batch) rng_gen(g, b0, lane);
-    double res = g.buf[slot];
+    uint32_t res = g.buf[slot];
     if ((int)((p0 + count - 1u) >> 8) != b0) {                // the pass crosses into the next 256 positions
         rng_gen(g, b0 + 1, lane);
-        const double v = g.buf[slot];
+        const uint32_t v = g.buf[slot];
         if ((int)(p >> 8) != b0) res = v;
     }
     return res;
@@ -185,15 +184,18 @@ constexpr int kSpecScalars = 16;   // 64-bit words of a chain's scalars handed f
 // queue slots: one per node of the component, plus one per further 8 neighbours of a node
 __host__ __device__ inline size_t queue_slots(int S, int E2) { return (size_t)S + (size_t)E2 / 8 + 8; }
 
-// The FIFO lives in LDS next to the tables; frames whose tables do not fit keep it in HBM too (a.slots_g), which
+// The FIFO lives in LDS next to the tables (one 32-bit word per slot: node | first CSR entry << 16; the entry count
+// follows from the row pointers); frames whose tables do not fit keep it in HBM (a.slots_g, 64-bit slots), which
 // leaves room for several chains per workgroup.
 // rec_lds: the per-superpixel records (88 B each) sit in LDS too; without them eight chains fit a workgroup
 // topo_lds: frames whose tables do not fit keep at least the CSR topology (row pointers, u16 columns) in LDS
-// spec: two waves per chain (the speculative form): labels and scalars are per chain, the rest per wave
+// nspec: wavefronts per chain (1 = the plain form; 2..4 = the speculative form): labels and scalars are per chain,
+//        the rest per wave
 __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool tab_lds, bool rec_lds, bool topo_lds = false,
-                                                 bool spec = false)
+                                                 int nspec = 1)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const bool spec = nspec > 1;
     LdsLayout L;
     size_t o = 0;
     L.fit = o; if (tab_lds && rec_lds) o += A((size_t)S * kRecStride * 8);
@@ -211,14 +213,14 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     o += cb * (size_t)wpb;
     L.wave0 = o;
     size_t w = 0;
-    L.w_slots = w; if (tab_lds) w += A(queue_slots(S, E2) * 8);
+    L.w_slots = w; if (tab_lds) w += A(queue_slots(S, E2) * 4);
     L.w_cl = w; w += A((size_t)S * 4);
     L.w_nflag = w; w += A((size_t)S);
     L.w_rbits = w; w += A(NW * 4);
     L.w_rpre = w; w += A(NW * 4);
-    L.w_rng = w; w += 4 * 64 * 8;
+    L.w_rng = w; w += 4 * 64 * 4;
     L.wave_bytes = w;
-    L.total = o + w * (size_t)wpb * (spec ? 2u : 1u);
+    L.total = o + w * (size_t)wpb * (size_t)(spec ? nspec : 1);
     return L;
 }
 
@@ -239,21 +241,25 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
 constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
 constexpr uint32_t kPartShift = 20u;       // FIFO slot word: node (16) | entries (4) | part (12)
 
-// SPEC: two wavefronts per chain.  A step's proposal is a pure function of (chain state, step index) -- the Philox
-// counter is (step, position) -- and at C2 about 94 % of the steps leave the state as it was, so a wave may
-// evaluate step t+1 against the state BEFORE step t has been decided and is right whenever t changes nothing.  Both
-// waves of a chain take step indices from a counter; a wave evaluates its step at once (read-only on the labels
-// and the segment cache, which belong to the chain; FIFO, claim words, flags and RNG batch are its own), then waits
-// for its turn -- steps commit strictly in order -- and, if an earlier step has changed the state meanwhile
-// (version word), evaluates again, now alone.  Committing (statistics, trace, relabel, cache rows, counters) is
-// the same code as in the one-wave form and runs in step order, so the chain is the same chain bit for bit; the
-// scalars it carries travel from wave to wave through LDS.  With one chain per SIMD the step is bound by the
-// latency of its dependent LDS round trips, and the second wave fills the issue slots the first leaves idle.
-// Waits are bounded: a wave that waits too long marks the chain failed (MCMC_E_DEVICE) instead of hanging.
-template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF, bool TOPO_LDS = false, bool SPEC = false>
-__global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
+// SPEC: NSPEC (2..4) wavefronts per chain.  A step's proposal is a pure function of (chain state, step index) -- the
+// Philox counter is (step, position) -- and at C2 about 94 % of the steps leave the state as it was, so a wave may
+// evaluate step t+1, t+2, ... against the state BEFORE the steps ahead of it have been decided and is right whenever
+// they change nothing.  The waves of a chain take step indices from a ticket counter; a wave evaluates its step at
+// once (read-only on the labels and the segment cache, which belong to the chain; FIFO, claim words, flags and RNG
+// batch are its own), then waits for its turn -- steps commit strictly in order.  A version word counts the changes
+// of the state (odd while a commit rewrites it): a wave whose evaluation was made against an older version
+// evaluates again as soon as it sees the new one, without waiting for its turn, so that after an accepted move the
+// waves behind it recover side by side, not one after the other.  Committing (statistics, trace, relabel, cache rows,
+// counters) is the same code as in the one-wave form and runs in step order, so the chain is the same chain bit for
+// bit; the scalars it carries travel from wave to wave through LDS.  With one chain per SIMD the step is bound by
+// the latency of its dependent LDS round trips, and the further waves fill the issue slots the first leaves idle.
+// Waits are bounded by lack of progress (no step of the chain committed for ~0.1 s): such a wave marks the chain
+// failed (MCMC_E_DEVICE) instead of hanging.
+template <int WPB, bool TAB_LDS, bool REC_LDS, bool PROF, bool TOPO_LDS = false, int NSPEC = 1>
+__global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a, int s_lds, int e2_lds)
 {
-    constexpr int NT = WPB * 64 * (SPEC ? 2 : 1);
+    constexpr bool SPEC = NSPEC > 1;
+    constexpr int NT = WPB * 64 * NSPEC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x;
     const int wave = uni(tid >> 6);            // scalar: addresses derived from it stay in SGPRs
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
     const int S = a.S[frame];
     const int E2 = (int)a.E2[frame];
     const int NW = (S + 31) / 32;
-    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, REC_LDS, TOPO_LDS, SPEC);
+    const LdsLayout L = make_layout(s_lds, e2_lds, WPB, TAB_LDS, REC_LDS, TOPO_LDS, NSPEC);
 
     const double* g_fit = a.fit + (size_t)frame * a.s_max * kFitStride;
     const double* g_q = a.q + (size_t)frame * a.e2_max;
@@ -307,13 +313,13 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
         if (lane == 0) *s_Sv = cnt;
         if (lane == 63) s_Sv[1] = (int)md;
     }
-    const int cw = SPEC ? (wave >> 1) : wave;      // chain within the workgroup
-    const int role = SPEC ? (wave & 1) : 0;        // which of the chain's two waves (SPEC)
+    const int cw = SPEC ? uni(wave / NSPEC) : wave;          // chain within the workgroup
+    const int role = SPEC ? wave - cw * NSPEC : 0;          // which of the chain's waves (SPEC)
     const int chain = chain0 + cw;
     unsigned char* cbase = smem + L.chain0 + (size_t)cw * L.chain_bytes;
     uint16_t* label = reinterpret_cast<uint16_t*>(cbase + L.c_label);
     unsigned long long* sscal = reinterpret_cast<unsigned long long*>(cbase + L.c_scal);   // SPEC only
-    volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(cbase + L.c_ctl);       // SPEC: next, committed, version, failed
+    volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(cbase + L.c_ctl);       // SPEC: next ticket, committed, version, failed
     uint16_t* g_label = a.label + (size_t)(chain < a.n_chains ? chain : 0) * a.s_max;
     if (chain < a.n_chains && role == 0) {
         // the chain's labels (and, in the speculative form, its scalars and control words) before anyone steps
@@ -355,10 +361,30 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
 
     // ---- wave-private state ----
     unsigned char* wbase = smem + L.wave0 + (size_t)wave * L.wave_bytes;
-    // FIFO of the growth: .x = node | entries << 16 (0..8, 4 bits) | part << 20 (12 bits: a node of up to
-    // kMaxDegree neighbours), .y = first CSR entry of the part
-    uint2* slots = TAB_LDS ? reinterpret_cast<uint2*>(wbase + L.w_slots)
-                           : reinterpret_cast<uint2*>(a.slots_g) + ((size_t)chain * (SPEC ? 2 : 1) + role) * queue_slots(s_lds, e2_lds);
+    // FIFO of the growth.  A slot stands for at most 8 neighbours of one node (a node with more takes consecutive
+    // slots, "parts").  In LDS a slot is one word, node | first CSR entry << 16 (S, E2 < 65536 whenever the tables
+    // fit LDS): the number of entries is min(8, rowp[node + 1] - first), and the slot is a node's first iff
+    // first == rowp[node].  In HBM (tables behind L2) a slot is .x = node | entries << 16 (4 bits) | part << 20
+    // (12 bits), .y = first CSR entry.
+    uint32_t* slots32 = reinterpret_cast<uint32_t*>(wbase + L.w_slots);
+    uint2* slots64 = reinterpret_cast<uint2*>(a.slots_g) + ((size_t)chain * NSPEC + role) * queue_slots(s_lds, e2_lds);
+    auto put_slot = [&](uint32_t idx, uint32_t node, uint32_t first, uint32_t cnt, uint32_t part) __attribute__((always_inline)) {
+        if constexpr (TAB_LDS) slots32[idx] = node | (first << 16);
+        else slots64[idx] = make_uint2(node | (cnt << 16) | (part << kPartShift), first);
+    };
+    // slot idx (valid = idx is a live slot; an idle lane reads slot 0 and gets cnt = 0)
+    auto get_slot = [&](uint32_t idx, bool valid, uint32_t& node, uint32_t& first, uint32_t& cnt) __attribute__((always_inline)) {
+        if constexpr (TAB_LDS) {
+            const uint32_t w = slots32[valid ? idx : 0u];
+            node = w & 0xFFFFu; first = w >> 16;
+            const uint32_t left = rowp[node + 1u] - first;
+            cnt = valid ? min(8u, left) : 0u;
+        } else {
+            const uint2 ent = slots64[valid ? idx : 0u];
+            node = ent.x & 0xFFFFu; first = ent.y;
+            cnt = valid ? ((ent.x >> 16) & 0xFu) : 0u;
+        }
+    };
     // appends to the FIFO are read by other lanes of this wave in a later pass
     auto queue_fence = [&]() {
         if constexpr (TAB_LDS) wave_fence(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -393,7 +419,7 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
     Rng g;
     g.k0 = a.seed; g.k1 = a.chain_offset + (uint32_t)chain;
     rng_keys(g);
-    g.buf = reinterpret_cast<double*>(wbase + L.w_rng);
+    g.buf = reinterpret_cast<uint32_t*>(wbase + L.w_rng);
 
     unsigned long long* marg = a.marg + (size_t)frame * a.s_max * a.lmax;
     unsigned long long* vh = a.visit_hash + (size_t)chain * a.hcap;
@@ -479,7 +505,11 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
 
     // the step's scratch (claim words of the component, neighbour flags) back to empty
     auto cleanup = [&]() __attribute__((always_inline)) {
-        for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) cl[slots[h].x & 0xFFFFu] = kFree;
+        for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) {
+            uint32_t node;
+            if constexpr (TAB_LDS) node = slots32[h] & 0xFFFFu; else node = slots64[h].x & 0xFFFFu;
+            cl[node] = kFree;
+        }
         for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
         wave_fence();
     };
@@ -504,25 +534,21 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
             sscal[13] = (unsigned long long)__double_as_longlong(last_targetL); sscal[14] = (unsigned long long)__double_as_longlong(last_prop);
         }
     };
-    constexpr uint32_t kSpinMax = 1u << 22;     // ~0.1 s of s_sleep: far beyond any step; then the chain is marked failed
+    // control words, read as wave-uniform scalars
+    auto ctl_rd = [&](int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[k]); };
+    // ~0.1 s of s_sleep polling WITHOUT any step of the chain being committed: far beyond any step (a commit that books
+    // visits in a large table included, since the count restarts whenever the chain advances); then the chain is marked failed
+    constexpr uint32_t kSpinMax = 1u << 22;
     bool failed = false;
     unsigned long long ts_next = 0;
     for (;;) {
         // ---- the step this wave takes ----
         unsigned long long ts;
-        uint32_t v0 = 0;
-        bool spec_live = false;
         if constexpr (SPEC) {
             uint32_t mine = 0;
             if (lane == 0) mine = atomicAdd(const_cast<uint32_t*>(ctl), 1u);
             ts = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
             if (ts >= total) break;
-            // a speculative evaluation needs a state that is not being rewritten (even version)
-            uint32_t spin = 0;
-            v0 = ctl[2];
-            while ((v0 & 1u) && spin < kSpinMax && ctl[3] == 0u) { __builtin_amdgcn_s_sleep(1); v0 = ctl[2]; ++spin; }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            spec_live = (int)(long long)sscal[8] == 0 && !(v0 & 1u);
         } else {
             ts = ts_next++;
             if (ts >= total) break;
@@ -536,22 +562,27 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
         for (int k = 0; k < kSumStride; ++k) { M2[k] = 0.0; M1[k] = 0.0; }
         const unsigned long long t = a.step0 + ts;
         bool evaluated = false;
-        // attempt 0: evaluate now (speculatively in the two-wave form); attempt 1 (two-wave form only): at this
-        // step's turn, once more if an earlier step has changed the state meanwhile
+        uint32_t v0 = 0;
+        // Plain form: one evaluation.  Speculative form: evaluate against the present version of the state, then wait
+        // for this step's turn; whenever a newer version shows up first, evaluate again at once.
 #pragma nounroll
-        for (int attempt = 0; attempt < (SPEC ? 2 : 1); ++attempt) {
+        for (;;) {
             bool need;
             if constexpr (SPEC) {
-                if (attempt == 0) need = spec_live;
-                else {
-                    uint32_t spin = 0;
-                    while (ctl[1] != (uint32_t)ts && spin < kSpinMax && ctl[3] == 0u) { __builtin_amdgcn_s_sleep(1); ++spin; }
-                    if (ctl[1] != (uint32_t)ts) { failed = true; if (lane == 0) ctl[3] = 1u; break; }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    load_scalars();
-                    need = status == 0 && (!evaluated || ctl[2] != v0);
-                    if (need && evaluated) cleanup();
+                // a state that is not being rewritten (even version)
+                uint32_t spin = 0, seen = ctl_rd(1);
+                uint32_t cur = ctl_rd(2);
+                while ((cur & 1u) && spin < kSpinMax && ctl_rd(3) == 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    cur = ctl_rd(2);
+                    const uint32_t c1 = ctl_rd(1);
+                    if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
                 }
+                if (cur & 1u) { failed = true; if (lane == 0) ctl[3] = 1u; break; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                need = (!evaluated || cur != v0) && (int)(long long)sscal[8] == 0;
+                if (need && evaluated) cleanup();
+                v0 = cur;
             } else {
                 need = status == 0;
             }
@@ -561,9 +592,9 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                 // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161); the step's other
                 // scalar draws are taken out of the batch now, before the growth moves on to later positions
                 start = vlist[(uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 0) % (uint32_t)Sv];
-                const double u1 = g.buf[2];
+                const double u1 = to_unit((uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 2));
                 const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 3);
-                const double r_mh = g.buf[4];
+                const double r_mh = to_unit((uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 4));
                 orig = label[start];
                 // the old segment's cache row (sums, probabilityL, size): in flight during the growth (a scalar load:
                 // as one vector load with lane k = entry k and v_readlane at the uses it measured 3 % slower)
@@ -584,7 +615,7 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                     const uint32_t rs0 = rowp[start], d0 = rowp[start + 1] - rs0;
                     const uint32_t parts0 = d0 <= 8u ? 1u : (d0 + 7u) >> 3;
                     for (uint32_t pp = (uint32_t)lane; pp < parts0; pp += kWave)
-                        slots[pp] = make_uint2(start | (min(8u, d0 - 8u * pp) << 16) | (pp << kPartShift), rs0 + 8u * pp);
+                        put_slot(pp, start, rs0 + 8u * pp, min(8u, d0 - 8u * pp), pp);
                     if (lane == 0) cl[start] = 0u;
                     qt = parts0;
                     queue_fence();
@@ -599,13 +630,13 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                         // claim this way are exactly those that would have found the node taken.  Trial positions are
                         // per slot, so the draws do not move.  (With everything in LDS this measured 5 % slower.)
                         const uint32_t K2 = min(qt - head, 16u);
-                        const uint2 entA = slots[head + g8];
-                        uint2 entB = make_uint2(0u, 0u);
-                        if (8u + g8 < K2) entB = slots[head + 8u + g8];
-                        const bool actA = s8 < ((entA.x >> 16) & 0xFu), actB = s8 < ((entB.x >> 16) & 0xFu);
-                        const uint32_t eA = actA ? entA.y + s8 : 0u, eB = actB ? entB.y + s8 : 0u;
-                        const double rA = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
-                        const double rB = rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), lane);
+                        uint32_t nodeA, firstA, cntA, nodeB, firstB, cntB;
+                        get_slot(head + g8, true, nodeA, firstA, cntA);
+                        get_slot(head + 8u + g8, 8u + g8 < K2, nodeB, firstB, cntB);
+                        const bool actA = s8 < cntA, actB = s8 < cntB;
+                        const uint32_t eA = actA ? firstA + s8 : 0u, eB = actB ? firstB + s8 : 0u;
+                        const double rA = to_unit(rng_trial(g, kTrialPos0 + 8u * head, 64u, lane));
+                        const double rB = to_unit(rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), lane));
                         const uint32_t jA = colAt(eA), jB = colAt(eB);
                         const double qxA = qv[eA], qxB = qv[eB];       // entry 0 for an idle lane: no branch around the load
                         const double qA = actA ? qxA : -1.0, qB = actB ? qxB : -1.0;
@@ -628,8 +659,8 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                             const uint64_t wmA = __ballot(winA), wmB = __ballot(winB);
                             const uint32_t nA = (uint32_t)__popcll((unsigned long long)wmA), nB = (uint32_t)__popcll((unsigned long long)wmB);
                             if (maxdeg <= 8u) {
-                                if (winA) slots[qt + (uint32_t)mbcnt(wmA)] = make_uint2(jA | (djA << 16), rjA);
-                                if (winB) slots[qt + nA + (uint32_t)mbcnt(wmB)] = make_uint2(jB | (djB << 16), rjB);
+                                if (winA) put_slot(qt + (uint32_t)mbcnt(wmA), jA, rjA, djA, 0u);
+                                if (winB) put_slot(qt + nA + (uint32_t)mbcnt(wmB), jB, rjB, djB, 0u);
                                 qt += nA + nB;
                             } else if (maxdeg <= 16u) {
                                 const bool bigA = winA && djA > 8u, bigB = winB && djB > 8u;
@@ -637,10 +668,10 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                                 const uint32_t tA = nA + (uint32_t)__popcll((unsigned long long)bmA);
                                 const uint32_t baseA = qt + (uint32_t)mbcnt(wmA) + (uint32_t)mbcnt(bmA);
                                 const uint32_t baseB = qt + tA + (uint32_t)mbcnt(wmB) + (uint32_t)mbcnt(bmB);
-                                if (winA) slots[baseA] = make_uint2(jA | (min(8u, djA) << 16), rjA);
-                                if (bigA) slots[baseA + 1u] = make_uint2(jA | ((djA - 8u) << 16) | (1u << kPartShift), rjA + 8u);
-                                if (winB) slots[baseB] = make_uint2(jB | (min(8u, djB) << 16), rjB);
-                                if (bigB) slots[baseB + 1u] = make_uint2(jB | ((djB - 8u) << 16) | (1u << kPartShift), rjB + 8u);
+                                if (winA) put_slot(baseA, jA, rjA, min(8u, djA), 0u);
+                                if (bigA) put_slot(baseA + 1u, jA, rjA + 8u, djA - 8u, 1u);
+                                if (winB) put_slot(baseB, jB, rjB, min(8u, djB), 0u);
+                                if (bigB) put_slot(baseB + 1u, jB, rjB + 8u, djB - 8u, 1u);
                                 qt += tA + nB + (uint32_t)__popcll((unsigned long long)bmB);
                             } else {
                                 const uint32_t partsA = winA ? (djA <= 8u ? 1u : (djA + 7u) >> 3) : 0u;
@@ -649,8 +680,8 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                                 const uint32_t tA = (uint32_t)__builtin_amdgcn_readlane((int)inclA, 63);
                                 const uint32_t baseA = qt + inclA - partsA, baseB = qt + tA + inclB - partsB;
                                 for (uint32_t pp = 0; pp < maxparts; ++pp) {
-                                    if (pp < partsA) slots[baseA + pp] = make_uint2(jA | (min(8u, djA - 8u * pp) << 16) | (pp << kPartShift), rjA + 8u * pp);
-                                    if (pp < partsB) slots[baseB + pp] = make_uint2(jB | (min(8u, djB - 8u * pp) << 16) | (pp << kPartShift), rjB + 8u * pp);
+                                    if (pp < partsA) put_slot(baseA + pp, jA, rjA + 8u * pp, min(8u, djA - 8u * pp), pp);
+                                    if (pp < partsB) put_slot(baseB + pp, jB, rjB + 8u * pp, min(8u, djB - 8u * pp), pp);
                                 }
                                 qt += tA + (uint32_t)__builtin_amdgcn_readlane((int)inclB, 63);
                             }
@@ -662,11 +693,11 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                         continue;
                     }
                     const uint32_t K = min(qt - head, 8u);
-                    uint2 ent = make_uint2(0u, 0u);
-                    if (g8 < K) ent = slots[head + g8];
-                    const bool act = s8 < ((ent.x >> 16) & 0xFu);
-                    const uint32_t e = act ? ent.y + s8 : 0u;
-                    const double r = rng_trial(g, kTrialPos0 + 8u * head, 64u, lane);
+                    uint32_t node, first, cnt;
+                    get_slot(head + g8, g8 < K, node, first, cnt);
+                    const bool act = s8 < cnt;
+                    const uint32_t e = act ? first + s8 : 0u;
+                    const double r = to_unit(rng_trial(g, kTrialPos0 + 8u * head, 64u, lane));
                     const uint32_t j = colAt(e);
                     const double qx = qv[e];                            // entry 0 for an idle lane: no branch around the load
                     const double qe = act ? qx : -1.0;
@@ -684,22 +715,22 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                         wave_fence();
                         const bool win = join && cl[j] == (uint32_t)lane;
                         const uint64_t wm = __ballot(win);
-                            if (maxdeg <= 8u) {
-                            if (win) slots[qt + (uint32_t)mbcnt(wm)] = make_uint2(j | (dj << 16), rj);
+                        if (maxdeg <= 8u) {
+                            if (win) put_slot(qt + (uint32_t)mbcnt(wm), j, rj, dj, 0u);
                             qt += (uint32_t)__popcll((unsigned long long)wm);
                         } else if (maxdeg <= 16u) {
                             const bool big = win && dj > 8u;
                             const uint64_t bm = __ballot(big);
                             const uint32_t base = qt + (uint32_t)mbcnt(wm) + (uint32_t)mbcnt(bm);
-                            if (win) slots[base] = make_uint2(j | (min(8u, dj) << 16), rj);
-                            if (big) slots[base + 1u] = make_uint2(j | ((dj - 8u) << 16) | (1u << kPartShift), rj + 8u);
+                            if (win) put_slot(base, j, rj, min(8u, dj), 0u);
+                            if (big) put_slot(base + 1u, j, rj + 8u, dj - 8u, 1u);
                             qt += (uint32_t)__popcll((unsigned long long)wm) + (uint32_t)__popcll((unsigned long long)bm);
                         } else {
                             const uint32_t parts = win ? (dj <= 8u ? 1u : (dj + 7u) >> 3) : 0u;
                             const uint32_t incl = wave_scan_add_u32(parts);
                             const uint32_t base = qt + incl - parts;
                             for (uint32_t pp = 0; pp < maxparts; ++pp)
-                                if (pp < parts) slots[base + pp] = make_uint2(j | (min(8u, dj - 8u * pp) << 16) | (pp << kPartShift), rj + 8u * pp);
+                                if (pp < parts) put_slot(base + pp, j, rj + 8u * pp, min(8u, dj - 8u * pp), pp);
                             qt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         }
                         qn += (uint32_t)__popcll((unsigned long long)wm);
@@ -755,18 +786,18 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                     // four blocks of 8 slots per trip: their LDS round trips overlap, the factors are applied in
                     // block order
                     for (uint32_t b8 = 0; b8 < qt; b8 += 32u) {
-                        uint2 ent[4];
+                        uint32_t first4[4], cnt4[4];
     #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const uint32_t sl = b8 + 8u * (uint32_t)u + g8;
-                            ent[u] = slots[sl < qt ? sl : 0u];
-                            if (sl >= qt) ent[u].x = 0u;
+                            uint32_t node;
+                            get_slot(sl, sl < qt, node, first4[u], cnt4[u]);
                         }
                         double qe[4]; uint32_t jj[4];
     #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const bool act = s8 < ((ent[u].x >> 16) & 0xFu);
-                            const uint32_t e = act ? ent[u].y + s8 : 0u;
+                            const bool act = s8 < cnt4[u];
+                            const uint32_t e = act ? first4[u] + s8 : 0u;
                             const double qx = qv[e];
                             qe[u] = act ? qx : -1.0;
                             jj[u] = colAt(e);
@@ -790,9 +821,16 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                     for (int k = 0; k < kSumStride; ++k) mc[k] = 0.0;
                     int mn = 0x7FFFFFFF;
                     for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) {
-                        const uint32_t ex = slots[h].x;
-                        if ((ex >> kPartShift) != 0u) continue;
-                        const uint32_t i = ex & 0xFFFFu;
+                        uint32_t i;
+                        if constexpr (TAB_LDS) {
+                            const uint32_t w = slots32[h];
+                            i = w & 0xFFFFu;
+                            if ((w >> 16) != rowp[i]) continue;
+                        } else {
+                            const uint32_t ex = slots64[h].x;
+                            if ((ex >> kPartShift) != 0u) continue;
+                            i = ex & 0xFFFFu;
+                        }
     #pragma unroll
                         for (int k = 0; k < kSumStride; ++k) mc[k] += recAt(i, k);
                         rp += recAt(i, kSumStride);
@@ -801,7 +839,7 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                     MC_PHASE(3);
                     const double sep = wave_prod_f64(ps);
                     const double mrg = kase == 2 ? wave_prod_f64(pm) : 1.0;
-                    // the eleven sums: the two-wave form, which is bound by instruction issue, folds them into one
+                    // the eleven sums: the speculative form, which is bound by instruction issue, folds them into one
                     // butterfly (device_math.hpp: the bits of eleven wave_sum_f64 for half the instructions, two LDS
                     // exchanges across rows; -0.6 % per step); the one-wave forms, bound by latency, measured 1 % slower
                     // with it and keep the eleven plain ones
@@ -870,8 +908,29 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
                 if (st != 0) accept = false;
                 evaluated = true;
             }
+            if constexpr (!SPEC) break;
+            else {
+                // this step's turn, or a newer state to evaluate against, whichever comes first
+                uint32_t spin = 0, seen = ctl_rd(1);
+                while (seen != (uint32_t)ts && ctl_rd(2) == v0 && spin < kSpinMax && ctl_rd(3) == 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    const uint32_t c1 = ctl_rd(1);
+                    if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
+                }
+                if (seen == (uint32_t)ts) {
+                    // every earlier step is committed: nobody else changes the state now
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    if (ctl_rd(2) == v0) break;
+                } else if (ctl_rd(2) == v0) {
+                    failed = true; if (lane == 0) ctl[3] = 1u;      // no progress (or another wave gave up)
+                    break;
+                }
+            }
         }
-        if constexpr (SPEC) { if (failed) break; }
+        if constexpr (SPEC) {
+            if (failed) break;
+            load_scalars();
+        }
 
         // ---- commit, in step order: MH bookkeeping, the jump if accepted, counters, trace ----
         uint8_t tb = 0xFF;
@@ -937,22 +996,27 @@ __global__ __launch_bounds__(WPB * 64 * (SPEC ? 2 : 1)) void chain_run_kernel(Ch
         }
         if (a.trace && lane == 0) a.trace[(size_t)chain * a.trace_stride + ts] = tb;
         if (ts >= a.burn_in && status == 0) dwell++;
-        if (evaluated) cleanup();
         if constexpr (SPEC) {
+            // the next step's turn begins before this wave tidies its own scratch
             store_scalars();
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             if (lane == 0) ctl[1] = (uint32_t)ts + 1u;
         }
+        if (evaluated) cleanup();
         MC_PHASE(11);
     }
     if constexpr (SPEC) {
         // the chain's first wave closes the run once every step is committed
         if (role != 0) return;
-        uint32_t spin = 0;
-        while (ctl[1] != (uint32_t)total && spin < kSpinMax && ctl[3] == 0u) { __builtin_amdgcn_s_sleep(1); ++spin; }
+        uint32_t spin = 0, seen = ctl_rd(1);
+        while (seen != (uint32_t)total && spin < kSpinMax && ctl_rd(3) == 0u) {
+            __builtin_amdgcn_s_sleep(1);
+            const uint32_t c1 = ctl_rd(1);
+            if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         load_scalars();
-        if (failed || ctl[1] != (uint32_t)total) status = -2;   // MCMC_E_DEVICE: a wait ran out (never seen; a hang otherwise)
+        if (failed || seen != (uint32_t)total) status = -2;   // MCMC_E_DEVICE: a wait ran out (never seen; a hang otherwise)
     }
     flush_stats();
     if constexpr (PROF) {
@@ -1223,7 +1287,7 @@ hipError_t launch_chain_init(const ChainArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int WPB, bool TAB, bool REC = TAB, bool PROF = false, bool TOPO = false, bool SPEC = false>
+template <int WPB, bool TAB, bool REC = TAB, bool PROF = false, bool TOPO = false, int NSPEC = 1>
 static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size_t bytes, hipStream_t st)
 {
     if constexpr (!PROF && WPB == 4 && TAB && REC) {
@@ -1232,13 +1296,13 @@ static hipError_t launch_variant(const ChainArgs& a, int s_lds, int e2_lds, size
     static DeviceOnce once;
     bool* attr_done = once.slot();
     if (!attr_done || !*attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, REC, PROF, TOPO, SPEC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_run_kernel<WPB, TAB, REC, PROF, TOPO, NSPEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit - 64);
         if (e != hipSuccess) return e;
         if (attr_done) *attr_done = true;
     }
     const int blocks = (a.n_chains + WPB - 1) / WPB;
-    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, REC, PROF, TOPO, SPEC>), dim3(blocks), dim3(WPB * 64 * (SPEC ? 2 : 1)), bytes, st, a, s_lds, e2_lds);
+    hipLaunchKernelGGL((chain_run_kernel<WPB, TAB, REC, PROF, TOPO, NSPEC>), dim3(blocks), dim3(WPB * 64 * NSPEC), bytes, st, a, s_lds, e2_lds);
     return hipGetLastError();
 }
 
@@ -1264,21 +1328,27 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
             const LdsLayout L8 = make_layout(s_used_max, e2_used_max, 8, true, false);
-            if (L8.total <= cap && (a.dense_variant > 0 || a.n_chains > 4 * cus)) {
+            if (L8.total <= cap && e2_used_max <= 0xFFFF && (a.dense_variant > 0 || a.n_chains > 4 * cus)) {
                 if (variant_out) *variant_out = 28;
                 return launch_variant<8, true, false>(a, s_used_max, e2_used_max, L8.total, st);
             }
         }
     }
-    // No more chains than four per CU, i.e. at most one wave per SIMD in the plain form: two waves per chain, the
-    // second evaluating the next step speculatively (see the kernel).  Records through L2, as in the dense form.
-    if (!a.prof && a.spec_variant >= 0 && a.chains_per_frame % 4 == 0 && a.burn_in + a.iters < 0xFFFFFFFFull) {
+    // No more chains than four per CU, i.e. at most one wave per SIMD in the plain form: several waves per chain, the
+    // further ones evaluating the next steps speculatively (see the kernel).  Records through L2, as in the dense form.
+    // spec_variant: 0 = as many waves as fit, up to kSpecAuto; 1 = the same whatever the chain count; 2..4 = exactly that many
+    if (!a.prof && a.spec_variant >= 0 && a.chains_per_frame % 4 == 0 && a.burn_in + a.iters < 0x7FFFFFFFull && e2_used_max <= 0xFFFF) {
         int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
-            const LdsLayout Ls = make_layout(s_used_max, e2_used_max, 4, true, false, false, true);
-            if (Ls.total <= cap && (a.spec_variant > 0 || a.n_chains <= 4 * cus)) {
-                if (variant_out) *variant_out = 44;
-                return launch_variant<4, true, false, false, false, true>(a, s_used_max, e2_used_max, Ls.total, st);
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            (a.spec_variant > 0 || a.n_chains <= 4 * cus)) {
+            const int hi = a.spec_variant >= 2 ? min(a.spec_variant, 4) : kSpecAuto, lo = a.spec_variant >= 2 ? hi : 2;
+            for (int ns = hi; ns >= lo; --ns) {
+                const LdsLayout Ls = make_layout(s_used_max, e2_used_max, 4, true, false, false, ns);
+                if (Ls.total > cap) continue;
+                if (variant_out) *variant_out = 44 + 100 * (ns - 2);
+                if (ns == 4) return launch_variant<4, true, false, false, false, 4>(a, s_used_max, e2_used_max, Ls.total, st);
+                if (ns == 3) return launch_variant<4, true, false, false, false, 3>(a, s_used_max, e2_used_max, Ls.total, st);
+                return launch_variant<4, true, false, false, false, 2>(a, s_used_max, e2_used_max, Ls.total, st);
             }
         }
     }
@@ -1302,7 +1372,7 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
             const int wpb = wpbs[wi];
             if (a.chains_per_frame % wpb) continue;
             const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, tab != 0, tab != 0);
-            if (L.total > cap) continue;
+            if (L.total > cap || (tab && e2_used_max > 0xFFFF)) continue;
             if (!tab && !a.slots_g) return hipErrorInvalidValue;
             if (variant_out) *variant_out = tab * 10 + wpb;
             if (tab) {
