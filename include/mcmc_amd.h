@@ -195,7 +195,7 @@ int mcmc_set_timing(mcmc_ctx *ctx, int enable);
  * "k1_threads", "k1_use_lds", "k1_debug", "k3_profile", "k3_dense" (eight chains per workgroup with the records
  * read through L2: -1 never, 0 when the chains exceed four per CU, 1 always), "k3_spec" (several waves per chain in
  * step order, the further ones evaluating the next steps against the undecided state: -1 never, 0 = as many as fit
- * LDS, up to three, when there are at most four chains per CU, 1 = the same whatever the chain count, 2..4 = exactly
+ * LDS, up to four, when there are at most four chains per CU, 1 = the same whatever the chain count, 2..4 = exactly
  * that many if they fit).  Results never depend on them. */
 int mcmc_ctx_set_option(mcmc_ctx *ctx, const char *name, int value);
 /* Diagnostic (no counterpart in the reference): which form of the chain kernel the last mcmc_chains_run

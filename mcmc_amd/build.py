@@ -24,6 +24,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 EXTRA = {"chain_kernels.hip": ["-mllvm", "-amdgpu-scalarize-global-loads=0",
                                "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true"]}
 OBJ = os.path.join(HERE, "_obj")
+# experiments only: MCMC_BUILD_DEFS="-DMC_SPEC_STATS" MCMC_BUILD_TAG=stats builds libmcmc_amd_stats.so beside the product
+# (objects in _obj_stats); host.load() takes MCMC_AMD_LIB=<path> to load it.  The product build never sets these.
+_TAG = os.environ.get("MCMC_BUILD_TAG", "")
+if _TAG:
+    LIB = os.path.join(HERE, "libmcmc_amd_%s.so" % _TAG)
+    OBJ = os.path.join(HERE, "_obj_%s" % _TAG)
+    FLAGS = FLAGS + os.environ.get("MCMC_BUILD_DEFS", "").split()
 
 
 def sources():

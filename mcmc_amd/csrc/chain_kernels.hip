@@ -29,7 +29,7 @@
 namespace mc {
 
 constexpr int kLdsLimit = 160 * 1024;
-constexpr int kSpecAuto = 3;    // waves per chain the speculative form takes by itself when they fit (up to 4 on request)
+constexpr int kSpecAuto = 4;    // waves per chain the speculative form takes by itself when they fit
 
 MC_D size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -42,31 +42,26 @@ struct Rng {
     uint32_t k0, k1, step_lo, step_hi;
     int batch;
     uint32_t* buf;                // LDS, [4][64]: the batch's raw 32-bit draws (1 KB; a draw becomes rand()/RAND_MAX at its use)
-    // the 10 round keys of the chain, pinned in vector registers: they are wave-uniform and loop-invariant, so the
-    // compiler would keep all 20 in SGPRs, run out, and park them in lanes of a spill VGPR -- a v_readlane and a
-    // hazard nop per round inside the growth loop.  From a VGPR the round's v_xor takes them as they are.
-    uint32_t kr0[10], kr1[10];
 };
-MC_D uint32_t pin_vgpr(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
-MC_D void rng_keys(Rng& g)
-{
-    uint32_t a = g.k0, b = g.k1;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) { g.kr0[r] = pin_vgpr(a); g.kr1[r] = pin_vgpr(b); a += kPhiloxW0; b += kPhiloxW1; }
-}
-// philox4x32_10 (device_math.hpp) with the key schedule of rng_keys
+// philox4x32_10 (device_math.hpp).  The 10 round keys are wave-uniform and loop-invariant, so the compiler would keep
+// all 20 in SGPRs across the growth loop, run out, and park them in lanes of a spill VGPR (a v_readlane and a hazard
+// nop per round); pinned in VGPRs they cost 20 registers of a kernel that wants four waves per SIMD.  Here the key
+// pair is hidden from the optimiser at every call, so the schedule is ten scalar adds per call that live nowhere.
 MC_D u32x4 philox_pinned(u32x4 c, const Rng& g)
 {
+    uint32_t a = g.k0, b = g.k1;
+    asm volatile("" : "+s"(a), "+s"(b));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)kPhiloxM0 * c.x;
         const uint64_t p1 = (uint64_t)kPhiloxM1 * c.z;
         u32x4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ g.kr0[r];
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ a;
         n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ g.kr1[r];
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ b;
         n.w = (uint32_t)p0;
         c = n;
+        a += kPhiloxW0; b += kPhiloxW1;
     }
     return c;
 }
@@ -176,9 +171,10 @@ struct SegFit {
 // ---------------------------------------------------------------------------
 struct LdsLayout {
     size_t fit, q, col, rowp, vlist, sv, chain0, chain_bytes, wave0, wave_bytes, total;
-    size_t c_label, c_scal, c_ctl;                       // per chain: labels, shared scalars, control words (SPEC)
+    size_t c_label, c_scal, c_ctl, c_ring;               // per chain: labels, shared scalars, control words, changed-label ring (SPEC)
     size_t w_slots, w_cl, w_nflag, w_rbits, w_rpre, w_rng;   // per wave
 };
+constexpr int kRingEntries = 4;    // accepted moves whose changed labels are remembered (a wave is at most three steps ahead)
 constexpr int kSpecScalars = 16;   // 64-bit words of a chain's scalars handed from wave to wave (speculative form)
 
 // queue slots: one per node of the component, plus one per further 8 neighbours of a node
@@ -209,12 +205,13 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     L.c_label = cb; cb += A((size_t)S * 2);
     L.c_scal = cb; if (spec) cb += (size_t)kSpecScalars * 8;
     L.c_ctl = cb; if (spec) cb += 16;
+    L.c_ring = cb; if (spec) cb += kRingEntries * 4 * 2;
     L.chain0 = o; L.chain_bytes = cb;
     o += cb * (size_t)wpb;
     L.wave0 = o;
     size_t w = 0;
     L.w_slots = w; if (tab_lds) w += A(queue_slots(S, E2) * 4);
-    L.w_cl = w; w += A((size_t)S * 4);
+    L.w_cl = w; w += A((size_t)S);
     L.w_nflag = w; w += A((size_t)S);
     L.w_rbits = w; w += A(NW * 4);
     L.w_rpre = w; w += A(NW * 4);
@@ -238,7 +235,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
         }                                                              \
     } while (0)
 
-constexpr uint32_t kFree = 0xFFFFFFFFu;   // cl[j]: superpixel j is not in the component
+constexpr uint32_t kFree = 0xFFu;          // cl[j] (one byte per superpixel): j is not in the component; else the lane that claimed it
 constexpr uint32_t kPartShift = 20u;       // FIFO slot word: node (16) | entries (4) | part (12)
 
 // SPEC: NSPEC (2..4) wavefronts per chain.  A step's proposal is a pure function of (chain state, step index) -- the
@@ -247,9 +244,12 @@ constexpr uint32_t kPartShift = 20u;       // FIFO slot word: node (16) | entrie
 // they change nothing.  The waves of a chain take step indices from a ticket counter; a wave evaluates its step at
 // once (read-only on the labels and the segment cache, which belong to the chain; FIFO, claim words, flags and RNG
 // batch are its own), then waits for its turn -- steps commit strictly in order.  A version word counts the changes
-// of the state (odd while a commit rewrites it): a wave whose evaluation was made against an older version
-// evaluates again as soon as it sees the new one, without waiting for its turn, so that after an accepted move the
-// waves behind it recover side by side, not one after the other.  Committing (statistics, trace, relabel, cache rows,
+// of the state (odd while a commit rewrites it).  An accepted move only touches the labels of the segments it involves
+// (old segment, target segment, the two new names), and it publishes those four labels before it rewrites anything; an
+// evaluation that has seen none of them -- its own segment and the neighbouring segments it flagged are all it ever
+// read -- is an evaluation of the new state as well and stays valid.  A wave whose evaluation did see one of them
+// evaluates again as soon as the new state is complete, without waiting for its turn, so that after an accepted move
+// the waves behind it recover side by side, not one after the other.  Committing (statistics, trace, relabel, cache rows,
 // counters) is the same code as in the one-wave form and runs in step order, so the chain is the same chain bit for
 // bit; the scalars it carries travel from wave to wave through LDS.  With one chain per SIMD the step is bound by
 // the latency of its dependent LDS round trips, and the further waves fill the issue slots the first leaves idle.
@@ -320,6 +320,8 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     uint16_t* label = reinterpret_cast<uint16_t*>(cbase + L.c_label);
     unsigned long long* sscal = reinterpret_cast<unsigned long long*>(cbase + L.c_scal);   // SPEC only
     volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(cbase + L.c_ctl);       // SPEC: next ticket, committed, version, failed
+    // SPEC: the labels an accepted move touched (old segment, target, the two new names), entry (version / 2) % kRingEntries
+    volatile uint16_t* ring = reinterpret_cast<volatile uint16_t*>(cbase + L.c_ring);
     uint16_t* g_label = a.label + (size_t)(chain < a.n_chains ? chain : 0) * a.s_max;
     if (chain < a.n_chains && role == 0) {
         // the chain's labels (and, in the speculative form, its scalars and control words) before anyone steps
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     auto queue_fence = [&]() {
         if constexpr (TAB_LDS) wave_fence(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     };
-    uint32_t* cl = reinterpret_cast<uint32_t*>(wbase + L.w_cl);          // kFree, or in the component
+    uint8_t* cl = wbase + L.w_cl;                                         // kFree, or in the component
+    uint32_t* clw = reinterpret_cast<uint32_t*>(wbase + L.w_cl);
     uint8_t* nflag = wbase + L.w_nflag;                                   // by label: 1 = neighbouring segment
     uint32_t* nflagw = reinterpret_cast<uint32_t*>(wbase + L.w_nflag);
     const int NWB = (int)(((size_t)S + 15) & ~(size_t)15) / 4;            // words of the flag array (zero padded)
@@ -398,8 +401,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
 
     // per-segment cache, row = the segment's name: 10 exact sums, sum of ssr, probabilityL, member count
     double* g_segC = a.segC + (size_t)chain * a.s_max * kSegCacheStride;
-    for (int i = lane; i < S; i += kWave) cl[i] = kFree;
-    for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
+    for (int w = lane; w < NWB; w += kWave) { clw[w] = 0xFFFFFFFFu; nflagw[w] = 0u; }
 
     double energy = a.energy[chain], best_energy = a.best_energy[chain];
     uint64_t state_hash = a.state_hash[chain], trace_hash = a.trace_hash[chain];
@@ -417,8 +419,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     const double log_var = det_log(var);
 
     Rng g;
-    g.k0 = a.seed; g.k1 = a.chain_offset + (uint32_t)chain;
-    rng_keys(g);
+    g.k0 = a.seed; g.k1 = uni(a.chain_offset + (uint32_t)chain);
     g.buf = reinterpret_cast<uint32_t*>(wbase + L.w_rng);
 
     unsigned long long* marg = a.marg + (size_t)frame * a.s_max * a.lmax;
@@ -498,17 +499,26 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     uint32_t start = 0, orig = 0, next = 0, csize = 0, qt = 0;
     int kase = 0, st = 0;
     bool have1 = false, accept = false;
-    double targetL = 0.0, prop = 0.0, R2 = 0.0, R1 = 0.0;
+    double targetL = 0.0, prop = 0.0;
     SegFit f1 = { 0.0, 0, 0, 0 }, f2 = { 0.0, 0, 0, 0 };
-    double M2[kSumStride], M1[kSumStride];
+    // the sums of the two proposed segments as cache rows, one entry per lane: lane l of every row of 16 lanes holds
+    // entry l & 15 (0..9 the exact sums, 10 the sum of ssr); a register pair each instead of twenty
+    double m2v = 0.0, m1v = 0.0;
+    // products: lane = 8 * slot + neighbour (the oracle's wave order of the factors)
     const uint32_t g8 = (uint32_t)lane >> 3, s8 = (uint32_t)lane & 7u;
+    // growth: FIFO place within a pass = 63 - lane, i.e. the first slot's first neighbour sits in lane 63.  When several
+    // lanes store to one LDS address in one instruction the highest lane's store is the one that lands on this hardware
+    // (tools/micro/lds_write_order.hip), so the claim of the first edge in FIFO order lands by itself; the arbitration
+    // below is correct whichever store lands and only repeats stores when it was another one.
+    const uint32_t rl = 63u - (uint32_t)lane;
+    const uint32_t gg8 = rl >> 3, gs8 = rl & 7u;
 
     // the step's scratch (claim words of the component, neighbour flags) back to empty
     auto cleanup = [&]() __attribute__((always_inline)) {
         for (uint32_t h = (uint32_t)lane; h < qt; h += kWave) {
             uint32_t node;
             if constexpr (TAB_LDS) node = slots32[h] & 0xFFFFu; else node = slots64[h].x & 0xFFFFu;
-            cl[node] = kFree;
+            cl[node] = (uint8_t)kFree;
         }
         for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
         wave_fence();
@@ -539,6 +549,9 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     // ~0.1 s of s_sleep polling WITHOUT any step of the chain being committed: far beyond any step (a commit that books
     // visits in a large table included, since the count restarts whenever the chain advances); then the chain is marked failed
     constexpr uint32_t kSpinMax = 1u << 22;
+#ifdef MC_SPEC_STATS
+    unsigned long long st_wait = 0, st_eval = 0, st_nev = 0, st_kept = 0, st_redo = 0, st_commit = 0, st_t0 = __builtin_readcyclecounter();
+#endif
     bool failed = false;
     unsigned long long ts_next = 0;
     for (;;) {
@@ -556,10 +569,8 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
         // nothing an evaluation hands to the commit outlives its step: said here, or the compiler carries every one of
         // these around the loop (registers and SGPR spills through the growth; 5 % of the eight-chain form's step)
         start = 0; orig = 0; next = 0; csize = 0; qt = 0; kase = 0; st = 0; have1 = false; accept = false;
-        targetL = 0.0; prop = 0.0; R2 = 0.0; R1 = 0.0;
+        targetL = 0.0; prop = 0.0; m2v = 0.0; m1v = 0.0;
         f1 = SegFit{ 0.0, 0, 0, 0 }; f2 = SegFit{ 0.0, 0, 0, 0 };
-#pragma unroll
-        for (int k = 0; k < kSumStride; ++k) { M2[k] = 0.0; M1[k] = 0.0; }
         const unsigned long long t = a.step0 + ts;
         bool evaluated = false;
         uint32_t v0 = 0;
@@ -586,21 +597,23 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
             } else {
                 need = status == 0;
             }
+#ifdef MC_SPEC_STATS
+            const unsigned long long st_e0 = __builtin_readcyclecounter();
+            if (need) { st_nev++; if (evaluated) st_redo++; }
+#endif
             if (need) {
                 g.step_lo = (uint32_t)t; g.step_hi = (uint32_t)(t >> 32);
                 const u32x4 raw0 = rng_gen(g, 0, lane);
                 // pickSuperPixel: rand() % S, then one unused draw (Segmentation.cpp:155,161); the step's other
                 // scalar draws are taken out of the batch now, before the growth moves on to later positions
                 start = vlist[(uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 0) % (uint32_t)Sv];
-                const double u1 = to_unit((uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 2));
+                const uint32_t u1_raw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 2);
                 const uint32_t idx_draw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 3);
-                const double r_mh = to_unit((uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 4));
+                const uint32_t mh_raw = (uint32_t)__builtin_amdgcn_readlane((int)raw0.x, 4);
                 orig = label[start];
-                // the old segment's cache row (sums, probabilityL, size): in flight during the growth (a scalar load:
-                // as one vector load with lane k = entry k and v_readlane at the uses it measured 3 % slower)
-                double Co[kSegCacheUsed];
-    #pragma unroll
-                for (int k = 0; k < kSegCacheUsed; ++k) Co[k] = g_segC[(size_t)orig * kSegCacheStride + k];
+                // the old segment's cache row (sums, sum of ssr, probabilityL, size), entry l & 15 in lane l: in flight
+                // during the growth, one register pair
+                const double co_v = g_segC[(size_t)orig * kSegCacheStride + ((uint32_t)lane & 15u)];
                 MC_PHASE(0);
 
                 // ---- createComponent BFS (Segmentation.cpp:74-120), 8 queue slots x 8 neighbours per pass ----
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     const uint32_t parts0 = d0 <= 8u ? 1u : (d0 + 7u) >> 3;
                     for (uint32_t pp = (uint32_t)lane; pp < parts0; pp += kWave)
                         put_slot(pp, start, rs0 + 8u * pp, min(8u, d0 - 8u * pp), pp);
-                    if (lane == 0) cl[start] = 0u;
+                    if (lane == 0) cl[start] = (uint8_t)0;
                     qt = parts0;
                     queue_fence();
                 }
@@ -624,19 +637,19 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     if (!TAB_LDS && qt - head > 8u) {
                         // Tables and FIFO behind L2 (large frames: long round trips, wide frontiers): two passes' worth
                         // of slots (head .. head+7 = A, head+8 .. head+15 = B) in one trip, so that their round trips
-                        // overlap.  The sequential order is kept by the claim priority (A's lanes 0..63 beat B's
-                        // 64..127: a node both reach goes to A, as it would if B ran after A) and by appending A's
+                        // overlap.  The sequential order is kept by the claim priority (every lane of A beats every lane
+                        // of B: a node both reach goes to A, as it would if B ran after A) and by appending A's
                         // winners before B's.  B reads the claim words before A's claims land; the lanes that lose the
                         // claim this way are exactly those that would have found the node taken.  Trial positions are
                         // per slot, so the draws do not move.  (With everything in LDS this measured 5 % slower.)
                         const uint32_t K2 = min(qt - head, 16u);
                         uint32_t nodeA, firstA, cntA, nodeB, firstB, cntB;
-                        get_slot(head + g8, true, nodeA, firstA, cntA);
-                        get_slot(head + 8u + g8, 8u + g8 < K2, nodeB, firstB, cntB);
-                        const bool actA = s8 < cntA, actB = s8 < cntB;
-                        const uint32_t eA = actA ? firstA + s8 : 0u, eB = actB ? firstB + s8 : 0u;
-                        const double rA = to_unit(rng_trial(g, kTrialPos0 + 8u * head, 64u, lane));
-                        const double rB = to_unit(rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), lane));
+                        get_slot(head + gg8, true, nodeA, firstA, cntA);
+                        get_slot(head + 8u + gg8, 8u + gg8 < K2, nodeB, firstB, cntB);
+                        const bool actA = gs8 < cntA, actB = gs8 < cntB;
+                        const uint32_t eA = actA ? firstA + gs8 : 0u, eB = actB ? firstB + gs8 : 0u;
+                        const double rA = to_unit(rng_trial(g, kTrialPos0 + 8u * head, 64u, (int)rl));
+                        const double rB = to_unit(rng_trial(g, kTrialPos0 + 8u * head + 64u, 8u * (K2 - 8u), (int)rl));
                         const uint32_t jA = colAt(eA), jB = colAt(eB);
                         const double qxA = qv[eA], qxB = qv[eB];       // entry 0 for an idle lane: no branch around the load
                         const double qA = actA ? qxA : -1.0, qB = actB ? qxB : -1.0;
@@ -651,39 +664,58 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                         if (freshB && lB != orig) nflag[lB] = 1;
                         const uint64_t jmA = __ballot(joinA), jmB = __ballot(joinB);
                         if (jmA | jmB) {
-                            if (joinA) atomicMin(&cl[jA], (uint32_t)lane);
-                            if (joinB) atomicMin(&cl[jB], 64u + (uint32_t)lane);
+                            // the first claimant of a node in FIFO order wins: tags 64 + lane for A, lane for B, the
+                            // highest tag is the first.  Byte stores, B's before A's; then every claimant looks at what
+                            // landed and a higher tag that lost stores again
+                            const uint32_t tagA = 64u + (uint32_t)lane, tagB = (uint32_t)lane;
+                            if (joinB) cl[jB] = (uint8_t)tagB;
                             wave_fence();
-                            const bool winA = joinA && cl[jA] == (uint32_t)lane;
-                            const bool winB = joinB && cl[jB] == 64u + (uint32_t)lane;
+                            if (joinA) cl[jA] = (uint8_t)tagA;
+                            wave_fence();
+                            uint32_t vA = joinA ? (uint32_t)cl[jA] : 0xFFu, vB = joinB ? (uint32_t)cl[jB] : 0xFFu;
+                            bool lostA = joinA && tagA > vA, lostB = joinB && tagB > vB;
+                            while (__ballot(lostA || lostB)) {
+                                if (lostB) cl[jB] = (uint8_t)tagB;
+                                wave_fence();
+                                if (joinA && tagA > (uint32_t)cl[jA]) cl[jA] = (uint8_t)tagA;
+                                wave_fence();
+                                vA = joinA ? (uint32_t)cl[jA] : 0xFFu; vB = joinB ? (uint32_t)cl[jB] : 0xFFu;
+                                lostA = joinA && tagA > vA; lostB = joinB && tagB > vB;
+                            }
+                            const bool winA = joinA && vA == tagA;
+                            const bool winB = joinB && vB == tagB;
                             const uint64_t wmA = __ballot(winA), wmB = __ballot(winB);
                             const uint32_t nA = (uint32_t)__popcll((unsigned long long)wmA), nB = (uint32_t)__popcll((unsigned long long)wmB);
+                            // winners are appended in FIFO order, i.e. by descending lane
+                            const uint32_t posA = nA - (uint32_t)mbcnt(wmA) - 1u, posB = nB - (uint32_t)mbcnt(wmB) - 1u;
                             if (maxdeg <= 8u) {
-                                if (winA) put_slot(qt + (uint32_t)mbcnt(wmA), jA, rjA, djA, 0u);
-                                if (winB) put_slot(qt + nA + (uint32_t)mbcnt(wmB), jB, rjB, djB, 0u);
+                                if (winA) put_slot(qt + posA, jA, rjA, djA, 0u);
+                                if (winB) put_slot(qt + nA + posB, jB, rjB, djB, 0u);
                                 qt += nA + nB;
                             } else if (maxdeg <= 16u) {
                                 const bool bigA = winA && djA > 8u, bigB = winB && djB > 8u;
                                 const uint64_t bmA = __ballot(bigA), bmB = __ballot(bigB);
-                                const uint32_t tA = nA + (uint32_t)__popcll((unsigned long long)bmA);
-                                const uint32_t baseA = qt + (uint32_t)mbcnt(wmA) + (uint32_t)mbcnt(bmA);
-                                const uint32_t baseB = qt + tA + (uint32_t)mbcnt(wmB) + (uint32_t)mbcnt(bmB);
+                                const uint32_t nbA = (uint32_t)__popcll((unsigned long long)bmA), nbB = (uint32_t)__popcll((unsigned long long)bmB);
+                                const uint32_t tA = nA + nbA;
+                                const uint32_t baseA = qt + posA + (nbA - (uint32_t)mbcnt(bmA) - (bigA ? 1u : 0u));
+                                const uint32_t baseB = qt + tA + posB + (nbB - (uint32_t)mbcnt(bmB) - (bigB ? 1u : 0u));
                                 if (winA) put_slot(baseA, jA, rjA, min(8u, djA), 0u);
                                 if (bigA) put_slot(baseA + 1u, jA, rjA + 8u, djA - 8u, 1u);
                                 if (winB) put_slot(baseB, jB, rjB, min(8u, djB), 0u);
                                 if (bigB) put_slot(baseB + 1u, jB, rjB + 8u, djB - 8u, 1u);
-                                qt += tA + nB + (uint32_t)__popcll((unsigned long long)bmB);
+                                qt += tA + nB + nbB;
                             } else {
                                 const uint32_t partsA = winA ? (djA <= 8u ? 1u : (djA + 7u) >> 3) : 0u;
                                 const uint32_t partsB = winB ? (djB <= 8u ? 1u : (djB + 7u) >> 3) : 0u;
                                 const uint32_t inclA = wave_scan_add_u32(partsA), inclB = wave_scan_add_u32(partsB);
                                 const uint32_t tA = (uint32_t)__builtin_amdgcn_readlane((int)inclA, 63);
-                                const uint32_t baseA = qt + inclA - partsA, baseB = qt + tA + inclB - partsB;
+                                const uint32_t tB = (uint32_t)__builtin_amdgcn_readlane((int)inclB, 63);
+                                const uint32_t baseA = qt + (tA - inclA), baseB = qt + tA + (tB - inclB);   // the parts of the lanes above
                                 for (uint32_t pp = 0; pp < maxparts; ++pp) {
                                     if (pp < partsA) put_slot(baseA + pp, jA, rjA + 8u * pp, min(8u, djA - 8u * pp), pp);
                                     if (pp < partsB) put_slot(baseB + pp, jB, rjB + 8u * pp, min(8u, djB - 8u * pp), pp);
                                 }
-                                qt += tA + (uint32_t)__builtin_amdgcn_readlane((int)inclB, 63);
+                                qt += tA + tB;
                             }
                             qn += nA + nB;
                             queue_fence();
@@ -694,10 +726,10 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     }
                     const uint32_t K = min(qt - head, 8u);
                     uint32_t node, first, cnt;
-                    get_slot(head + g8, g8 < K, node, first, cnt);
-                    const bool act = s8 < cnt;
-                    const uint32_t e = act ? first + s8 : 0u;
-                    const double r = to_unit(rng_trial(g, kTrialPos0 + 8u * head, 64u, lane));
+                    get_slot(head + gg8, gg8 < K, node, first, cnt);
+                    const bool act = gs8 < cnt;
+                    const uint32_t e = act ? first + gs8 : 0u;
+                    const double r = to_unit(rng_trial(g, kTrialPos0 + 8u * head, 64u, (int)rl));
                     const uint32_t j = colAt(e);
                     const double qx = qv[e];                            // entry 0 for an idle lane: no branch around the load
                     const double qe = act ? qx : -1.0;
@@ -710,43 +742,58 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     if (fresh && lj != orig) nflag[lj] = 1;
                     const uint64_t jm0 = __ballot(join);
                     if (jm0) {
-                        // several lanes may hold an open edge to the same node: the first in FIFO order takes it
-                        if (join) atomicMin(&cl[j], (uint32_t)lane);
+                        // several lanes may hold an open edge to the same node: the first in FIFO order -- the highest
+                        // lane -- takes it.  Byte stores, then every claimant looks at what landed and a higher lane
+                        // that lost stores again: the claim byte ends as the highest claiming lane whichever store the
+                        // hardware lets land (on gfx950 the highest lane's, so nothing is stored twice)
+                        if (join) cl[j] = (uint8_t)lane;
                         wave_fence();
-                        const bool win = join && cl[j] == (uint32_t)lane;
+                        uint32_t v = join ? (uint32_t)cl[j] : 0xFFu;
+                        bool lost = join && (uint32_t)lane > v;
+                        while (__ballot(lost)) {
+                            if (lost) cl[j] = (uint8_t)lane;
+                            wave_fence();
+                            v = join ? (uint32_t)cl[j] : 0xFFu;
+                            lost = join && (uint32_t)lane > v;
+                        }
+                        const bool win = join && v == (uint32_t)lane;
                         const uint64_t wm = __ballot(win);
+                        const uint32_t nw = (uint32_t)__popcll((unsigned long long)wm);
+                        const uint32_t pos = nw - (uint32_t)mbcnt(wm) - 1u;      // winners in FIFO order = by descending lane
                         if (maxdeg <= 8u) {
-                            if (win) put_slot(qt + (uint32_t)mbcnt(wm), j, rj, dj, 0u);
-                            qt += (uint32_t)__popcll((unsigned long long)wm);
+                            if (win) put_slot(qt + pos, j, rj, dj, 0u);
+                            qt += nw;
                         } else if (maxdeg <= 16u) {
                             const bool big = win && dj > 8u;
                             const uint64_t bm = __ballot(big);
-                            const uint32_t base = qt + (uint32_t)mbcnt(wm) + (uint32_t)mbcnt(bm);
+                            const uint32_t nb = (uint32_t)__popcll((unsigned long long)bm);
+                            const uint32_t base = qt + pos + (nb - (uint32_t)mbcnt(bm) - (big ? 1u : 0u));
                             if (win) put_slot(base, j, rj, min(8u, dj), 0u);
                             if (big) put_slot(base + 1u, j, rj + 8u, dj - 8u, 1u);
-                            qt += (uint32_t)__popcll((unsigned long long)wm) + (uint32_t)__popcll((unsigned long long)bm);
+                            qt += nw + nb;
                         } else {
                             const uint32_t parts = win ? (dj <= 8u ? 1u : (dj + 7u) >> 3) : 0u;
                             const uint32_t incl = wave_scan_add_u32(parts);
-                            const uint32_t base = qt + incl - parts;
+                            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            const uint32_t base = qt + (tot - incl);             // the parts of the lanes above
                             for (uint32_t pp = 0; pp < maxparts; ++pp)
                                 if (pp < parts) put_slot(base + pp, j, rj + 8u * pp, min(8u, dj - 8u * pp), pp);
-                            qt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            qt += tot;
                         }
-                        qn += (uint32_t)__popcll((unsigned long long)wm);
+                        qn += nw;
                         queue_fence();
                     }
                     head += K;
                     if constexpr (PROF) pacc[15] += 1;
                 }
                 csize = qn;
-                const uint32_t segn_orig = (uint32_t)Co[kSegCacheN];
+                const uint32_t segn_orig = (uint32_t)readlane_f64(co_v, kSegCacheN);
                 const bool same = csize == segn_orig;  // Segmentation.cpp:19
                 MC_PHASE(1);
 
                 // ---- selectSegment (Segmentation.cpp:10-57) ----
                 next = orig; double ratio;
-                if (!same && u1 < nsp) { kase = 1; ratio = nsp; }
+                if (!same && to_unit(u1_raw) < nsp) { kase = 1; ratio = nsp; }
                 else {
                     int nnl = 0;
                     for (int w = lane; w < NWB; w += kWave) nnl += __popc(nflagw[w]);
@@ -762,24 +809,15 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                 targetL = 1.0; prop = ratio;  // Case A (Problem.cpp:161-171): targetRatio = 1.0 (sic)
                 double logprop = 0.0;
                 f1 = SegFit{ 0.0, 0, 0, 0 }; f2 = SegFit{ 0.0, 0, 0, 0 };
-                R2 = 0.0; R1 = 0.0;
-    #pragma unroll
-                for (int k = 0; k < kSumStride; ++k) { M2[k] = 0.0; M1[k] = 0.0; }
+                m2v = 0.0; m1v = 0.0;
                 st = 0;
                 have1 = !same;  // sB1 = sA1 minus the component is not empty
                 if (kase != 0) {
                     // cached row of the target segment (Segment::combine / diff on sums instead of a refit from
                     // the member list, Graph.cpp:35-67): issued now, needed after the pass over the component
-                    // (one branch around the whole row: written as a select per entry it became thirteen loads, each
-                    // behind a branch of its own)
-                    double Cn[kSegCacheUsed];
-    #pragma unroll
-                    for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = 0.0;
-                    if (kase == 2) {
-                        const double* row = g_segC + (size_t)next * kSegCacheStride;
-    #pragma unroll
-                        for (int k = 0; k < kSegCacheUsed; ++k) Cn[k] = row[k];
-                    }
+                    // (entry l & 15 in lane l, as the old segment's)
+                    double cn_v = 0.0;
+                    if (kase == 2) cn_v = g_segC[(size_t)next * kSegCacheStride + ((uint32_t)lane & 15u)];
                     // separation / merge products over the component's cut edges (Segmentation.cpp:127-146;
                     // Graph.cpp:10-33), wave order over the examined-edge queue
                     double ps = 1.0, pm = 1.0;
@@ -839,39 +877,31 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     MC_PHASE(3);
                     const double sep = wave_prod_f64(ps);
                     const double mrg = kase == 2 ? wave_prod_f64(pm) : 1.0;
-                    // the eleven sums: the speculative form, which is bound by instruction issue, folds them into one
-                    // butterfly (device_math.hpp: the bits of eleven wave_sum_f64 for half the instructions, two LDS
-                    // exchanges across rows; -0.6 % per step); the one-wave forms, bound by latency, measured 1 % slower
-                    // with it and keep the eleven plain ones
-                    double sums[kSumStride + 1];
+                    // the eleven sums in one folded butterfly (device_math.hpp: the bits of eleven wave_sum_f64 for half
+                    // the instructions), left one per lane: entry l & 15 in lane l, like the cache rows
+                    double part[kSumStride + 1];
     #pragma unroll
-                    for (int k = 0; k < kSumStride; ++k) sums[k] = mc[k];
-                    sums[kSumStride] = rp;
-                    if constexpr (SPEC) wave_sum11_f64(sums, lane);
-                    else {
-    #pragma unroll
-                        for (int k = 0; k <= kSumStride; ++k) sums[k] = wave_sum_f64(sums[k]);
-                    }
-    #pragma unroll
-                    for (int k = 0; k < kSumStride; ++k) mc[k] = sums[k];
-                    const double Rc = sums[kSumStride];
+                    for (int k = 0; k < kSumStride; ++k) part[k] = mc[k];
+                    part[kSumStride] = rp;
+                    const double sv = wave_sum11_lanes_f64(part, lane);
                     const int minC = wave_min_i32(mn);
                     MC_PHASE(4);
-    #pragma unroll
-                    for (int k = 0; k < kSumStride; ++k) { M2[k] = kase == 2 ? Cn[k] + mc[k] : mc[k]; M1[k] = Co[k] - mc[k]; }
-                    R2 = kase == 2 ? Cn[kSumStride] + Rc : Rc;
-                    R1 = Co[kSumStride] - Rc;
+                    // Segment::combine / diff on sums (Graph.cpp:35-67): sB2 = sA2 + C (or C alone), sB1 = sA1 - C
+                    m2v = kase == 2 ? cn_v + sv : sv;
+                    m1v = co_v - sv;
                     if (kase == 1) prop = ratio * (1.0 / sep);              // Problem.cpp:188
                     else prop = ratio * (mrg / sep);                        // Problem.cpp:206
                     // the two evaluations run side by side: lanes 0..31 take sB2, lanes 32..63 sB1; the three
                     // pivot logarithms of each and log(proposal ratio) are taken by different lane groups
                     {
                         const bool hi = lane >= 32 && have1;   // without sB1 both halves evaluate sB2
-                        Sym3 A = { hi ? M1[0] : M2[0], hi ? M1[1] : M2[1], hi ? M1[2] : M2[2],
-                                   hi ? M1[3] : M2[3], hi ? M1[4] : M2[4], hi ? M1[5] : M2[5] };
-                        Vec3 rr = { hi ? M1[6] : M2[6], hi ? M1[7] : M2[7], hi ? M1[8] : M2[8] }, th, d;
+                        // entry k of the segment a half evaluates, to every lane of the half (LDS crossbar, no vector op)
+                        const double zv = hi ? m1v : m2v;
+                        Sym3 A = { bcast_half_f64<0>(zv), bcast_half_f64<1>(zv), bcast_half_f64<2>(zv),
+                                   bcast_half_f64<3>(zv), bcast_half_f64<4>(zv), bcast_half_f64<5>(zv) };
+                        Vec3 rr = { bcast_half_f64<6>(zv), bcast_half_f64<7>(zv), bcast_half_f64<8>(zv) }, th, d;
                         const double quad = ldl3(A, rr, th, d);
-                        const double err = (((hi ? M1[9] : M2[9]) - quad) - (hi ? R1 : R2)) / (2.0 * var);
+                        const double err = ((bcast_half_f64<9>(zv) - quad) - bcast_half_f64<10>(zv)) / (2.0 * var);
                         const int gg = (lane >> 3) & 3;
                         const double lx = det_log(gg == 0 ? d.x : (gg == 1 ? d.y : (gg == 2 ? d.z : prop)));
                         logprop = readlane_f64(lx, 24);
@@ -884,13 +914,13 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                         f2.probL = p2; f2.inf_flag = (p2 - p2 != 0.0) ? 1 : 0;   // Graph.cpp:137
                         f1.probL = have1 ? p1 : 0.0; f1.inf_flag = (have1 && p1 - p1 != 0.0) ? 1 : 0;
                     }
-                    f2.n = (int)csize + (kase == 2 ? (int)Cn[kSegCacheN] : 0);
+                    f2.n = (int)csize + (kase == 2 ? (int)readlane_f64(cn_v, kSegCacheN) : 0);
                     f2.minid = (kase == 2 && (int)next < minC) ? (int)next : minC;
                     f1.n = have1 ? (int)segn_orig - (int)csize : 0;
                     MC_PHASE(5);
                     // jumpProbability (Problem.cpp:475-487)
-                    const double sB2_sA1 = f2.probL - Co[kSegCacheP];
-                    const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? Cn[kSegCacheP] : 0.0);
+                    const double sB2_sA1 = f2.probL - readlane_f64(co_v, kSegCacheP);
+                    const double sB1_sA2 = (have1 ? f1.probL : 0.0) - (kase == 2 ? readlane_f64(cn_v, kSegCacheP) : 0.0);
                     targetL = sB2_sA1 + sB1_sA2;
                     if (f1.inf_flag || f2.inf_flag) st = -5;
                     if (targetL != targetL || prop != prop) st = -4;        // Problem.cpp:216-217
@@ -902,31 +932,69 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                 if (kase == 0) logprop = det_log(prop);
                 const double aL = targetL + logprop;
                 const double acc = det_exp(aL);
-                const double r = r_mh;  // always drawn
+                const double r = to_unit(mh_raw);  // always drawn
                 accept = true;
                 if (aL < 0.0) { if (r > acc) accept = false; }
                 if (st != 0) accept = false;
                 evaluated = true;
             }
+#ifdef MC_SPEC_STATS
+            const unsigned long long st_w0 = __builtin_readcyclecounter();
+            if (need) st_eval += st_w0 - st_e0;
+#endif
             if constexpr (!SPEC) break;
             else {
-                // this step's turn, or a newer state to evaluate against, whichever comes first
-                uint32_t spin = 0, seen = ctl_rd(1);
-                while (seen != (uint32_t)ts && ctl_rd(2) == v0 && spin < kSpinMax && ctl_rd(3) == 0u) {
-                    __builtin_amdgcn_s_sleep(1);
-                    const uint32_t c1 = ctl_rd(1);
-                    if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
-                }
-                if (seen == (uint32_t)ts) {
-                    // every earlier step is committed: nobody else changes the state now
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    if (ctl_rd(2) == v0) break;
-                } else if (ctl_rd(2) == v0) {
+                // this step's turn, or a change of the state, whichever comes first
+                bool redo = false;
+                for (;;) {
+                    uint32_t spin = 0, seen = ctl_rd(1);
+                    uint32_t cur = ctl_rd(2);
+                    while (seen != (uint32_t)ts && cur == v0 && spin < kSpinMax && ctl_rd(3) == 0u) {
+                        __builtin_amdgcn_s_sleep(1);
+                        const uint32_t c1 = ctl_rd(1);
+                        if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
+                        cur = ctl_rd(2);
+                    }
+                    if (cur != v0) {
+                        // accepted moves since this evaluation (the last one perhaps still being written: its labels
+                        // were published before the version went odd): did it read anything they touch?
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        bool ok = evaluated;
+                        if (evaluated) {
+                            for (uint32_t k = v0 >> 1; k < ((cur + 1u) >> 1); ++k) {
+                                const volatile uint16_t* d = ring + (k & (uint32_t)(kRingEntries - 1)) * 4u;
+    #pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const uint32_t dl = d[c];
+                                    ok = ok && dl != orig && nflag[dl] == 0;
+                                }
+                            }
+                        }
+#ifdef MC_SPEC_STATS
+                        if (__builtin_amdgcn_readfirstlane((int)ok)) st_kept++;
+#endif
+                        if (__builtin_amdgcn_readfirstlane((int)ok)) { v0 = (cur + 1u) & ~1u; continue; }   // still an evaluation of the newest state
+                        redo = true;
+                        break;
+                    }
+                    if (seen == (uint32_t)ts) {
+                        // every earlier step is committed: nobody else changes the state now
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        if (ctl_rd(2) == v0) break;
+                        continue;                                  // the last commit ahead changed it: look at what it touched
+                    }
                     failed = true; if (lane == 0) ctl[3] = 1u;      // no progress (or another wave gave up)
                     break;
                 }
+#ifdef MC_SPEC_STATS
+                st_wait += __builtin_readcyclecounter() - st_w0;
+#endif
+                if (!redo) break;
             }
         }
+#ifdef MC_SPEC_STATS
+        const unsigned long long st_c0 = __builtin_readcyclecounter();
+#endif
         if constexpr (SPEC) {
             if (failed) break;
             load_scalars();
@@ -941,7 +1009,6 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
             uint32_t newlab = next;
             if (accept && kase != 0) {
                 flush_stats();  // leaving the current state
-                if constexpr (SPEC) { if (lane == 0) ctl[2] = ctl[2] + 1u; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // odd: the state is being rewritten
                 MC_PHASE(9);
                 // jump (Problem.cpp:32-74) with smallest-member naming
                 const uint32_t L2 = (uint32_t)f2.minid;
@@ -951,6 +1018,16 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     for (int i = lane; i < S; i += kWave)
                         if (label[i] == orig && cl[i] == kFree) m1 = min(m1, i);
                     L1 = (uint32_t)wave_min_i32(m1);
+                }
+                if constexpr (SPEC) {
+                    // what this move touches, then odd: the state is being rewritten
+                    if (lane == 0) {
+                        const uint32_t v = ctl[2];
+                        volatile uint16_t* d = ring + ((v >> 1) & (uint32_t)(kRingEntries - 1)) * 4u;
+                        d[0] = (uint16_t)orig; d[1] = (uint16_t)(kase == 2 ? next : orig); d[2] = (uint16_t)L2; d[3] = (uint16_t)L1;
+                        ctl[2] = v + 1u;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 }
                 uint64_t dh = 0;
                 for (int i = lane; i < S; i += kWave) {
@@ -968,10 +1045,8 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                 // the new segments' rows go to the cache; the stores are complete before any later step of
                 // this wave reads them back (same CU, same L1: workgroup scope)
                 if (lane < kSegCacheUsed) {
-                    double v2 = (double)f2.n, v1 = (double)f1.n;
-#pragma unroll
-                    for (int k = 0; k < kSumStride; ++k) if (lane == k) { v2 = M2[k]; v1 = M1[k]; }
-                    if (lane == kSumStride) { v2 = R2; v1 = R1; }
+                    double v2 = m2v, v1 = m1v;                  // entries 0..10 as they are
+                    if (lane == kSegCacheN) { v2 = (double)f2.n; v1 = (double)f1.n; }
                     if (lane == kSegCacheP) { v2 = f2.probL; v1 = f1.probL; }
                     g_segC[(size_t)L2 * kSegCacheStride + lane] = v2;
                     if (have1) g_segC[(size_t)L1 * kSegCacheStride + lane] = v1;
@@ -1002,9 +1077,18 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             if (lane == 0) ctl[1] = (uint32_t)ts + 1u;
         }
+#ifdef MC_SPEC_STATS
+        st_commit += __builtin_readcyclecounter() - st_c0;
+#endif
         if (evaluated) cleanup();
         MC_PHASE(11);
     }
+#ifdef MC_SPEC_STATS
+    if (lane == 0 && a.prof) {
+        atomicAdd(a.prof + 0, st_wait); atomicAdd(a.prof + 1, st_eval); atomicAdd(a.prof + 2, st_nev); atomicAdd(a.prof + 3, st_kept);
+        atomicAdd(a.prof + 4, st_redo); atomicAdd(a.prof + 5, st_commit); atomicAdd(a.prof + 6, __builtin_readcyclecounter() - st_t0);
+    }
+#endif
     if constexpr (SPEC) {
         // the chain's first wave closes the run once every step is committed
         if (role != 0) return;
@@ -1337,7 +1421,12 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
     // No more chains than four per CU, i.e. at most one wave per SIMD in the plain form: several waves per chain, the
     // further ones evaluating the next steps speculatively (see the kernel).  Records through L2, as in the dense form.
     // spec_variant: 0 = as many waves as fit, up to kSpecAuto; 1 = the same whatever the chain count; 2..4 = exactly that many
-    if (!a.prof && a.spec_variant >= 0 && a.chains_per_frame % 4 == 0 && a.burn_in + a.iters < 0x7FFFFFFFull && e2_used_max <= 0xFFFF) {
+#ifdef MC_SPEC_STATS
+    if (a.spec_variant >= 0 && a.chains_per_frame % 4 == 0
+#else
+    if (!a.prof && a.spec_variant >= 0 && a.chains_per_frame % 4 == 0
+#endif
+    && a.burn_in + a.iters < 0x7FFFFFFFull && e2_used_max <= 0xFFFF) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
             (a.spec_variant > 0 || a.n_chains <= 4 * cus)) {

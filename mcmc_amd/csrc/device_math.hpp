@@ -273,8 +273,8 @@ MC_D double fold_f64(double a, double b, int lane)
     const double keep = hi ? b : a, send = hi ? a : b;
     return keep + xchg_f64<STAGE>(send);
 }
-// v[0..10] -> their wave sums (every lane gets all eleven)
-MC_D void wave_sum11_f64(double (&v)[11], int lane)
+// v[0..10] -> their wave sums, one per lane: lane l of every row of 16 lanes returns the sum of v[l & 15] (0 for 11..15)
+MC_D double wave_sum11_lanes_f64(const double (&v)[11], int lane)
 {
     const double w0 = fold_f64<0>(v[0], v[1], lane), w1 = fold_f64<0>(v[2], v[3], lane), w2 = fold_f64<0>(v[4], v[5], lane),
                  w3 = fold_f64<0>(v[6], v[7], lane), w4 = fold_f64<0>(v[8], v[9], lane), w5 = fold_f64<0>(v[10], 0.0, lane);
@@ -283,8 +283,24 @@ MC_D void wave_sum11_f64(double (&v)[11], int lane)
     double r = fold_f64<3>(t0, t1, lane);
     r = r + __shfl_xor(r, 16, kWave);
     r = r + __shfl_xor(r, 32, kWave);
+    return r;
+}
+// v[0..10] -> their wave sums (every lane gets all eleven)
+MC_D void wave_sum11_f64(double (&v)[11], int lane)
+{
+    const double r = wave_sum11_lanes_f64(v, lane);
 #pragma unroll
     for (int k = 0; k < 11; ++k) v[k] = readlane_f64(r, k);
+}
+// every lane of a half of the wave (lanes 0..31, lanes 32..63) gets the value of lane K of its half: the LDS crossbar's
+// swizzle in bit-mask mode (and 0, or K, xor 0), no memory access and no vector-pipe slot
+template <int K>
+MC_D double bcast_half_f64(double v)
+{
+    const uint64_t u = d2u(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)u, (K << 5));
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)(u >> 32), (K << 5));
+    return u2d(((uint64_t)hi << 32) | lo);
 }
 MC_D uint64_t wave_sum_u64(uint64_t v)
 {

@@ -90,7 +90,7 @@ struct ChainArgs {
     unsigned long long* slots_g; // [C][queue slots] FIFO of the growth when the frame's tables do not fit LDS (else unused)
     unsigned long long* prof;  // optional: 12 per-phase cycle sums (diagnostic build of the 4-wave LDS variant)
     int hcap, lmax;
-    int spec_variant;          // several waves per chain, speculating on the next steps: -1 never, 0 as many as fit (up to 3) when the chains are at most four per CU, 1 the same whatever the chain count, 2..4 exactly that many
+    int spec_variant;          // several waves per chain, speculating on the next steps: -1 never, 0 as many as fit (up to 4) when the chains are at most four per CU, 1 the same whatever the chain count, 2..4 exactly that many
     int dense_variant;         // eight chains per workgroup with the records in L2: -1 never, 0 when the chains exceed four per CU, 1 always
 };
 

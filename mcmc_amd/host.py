@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmcmc_amd.so")
+LIB_PATH = os.environ.get("MCMC_AMD_LIB") or os.path.join(HERE, "libmcmc_amd.so")   # MCMC_AMD_LIB: tuning builds only
 
 NOLABEL = 0xFFFF
 K_MOMENTS, K_LOCAL_FIT, K_EDGE_PROB, K_CHAIN = 0, 1, 2, 3

@@ -207,12 +207,12 @@ def test_chain_parity_small(scene_c2_small, gpu_ctx_factory):
     assert np.array_equal(ctx.marginals(0)[:sc.n_superpixels], orc.marginals())
 
 
-@pytest.mark.parametrize("dense,spec,variant", [(1, -1, 28), (-1, -1, 14), (-1, 0, 144), (-1, 1, 144), (-1, 2, 44), (-1, 3, 144),
+@pytest.mark.parametrize("dense,spec,variant", [(1, -1, 28), (-1, -1, 14), (-1, 0, 244), (-1, 1, 244), (-1, 2, 44), (-1, 3, 144),
                                                 (-1, 4, 244)])
 def test_chain_parity_dense_variant(scene_c2_small, gpu_ctx_factory, dense, spec, variant):
     # eight chains per workgroup with the per-superpixel records read through L2 (picked by itself when the chains
     # exceed four per CU; forced here); the plain form (four chains per workgroup, everything in LDS); and the
-    # speculative form (two, three or four waves per chain in step order; three are picked by themselves when the
+    # speculative form (two, three or four waves per chain in step order; four are picked by themselves when the
     # chains are at most four per CU and the state fits; variant = 44 + 100 * (waves - 2)): identical chains
     sc = scene_c2_small
     ctx = gpu_ctx_factory(width=sc.width, height=sc.height)
@@ -235,9 +235,9 @@ def test_chain_parity_dense_variant(scene_c2_small, gpu_ctx_factory, dense, spec
 
 
 def test_chain_parity_speculative_form_long_run(gpu_ctx_factory):
-    # the speculative form (three waves per chain at this size, in-order commit) at C2 size against the oracle over runs long
+    # the speculative form (four waves per chain at this size, in-order commit) at C2 size against the oracle over runs long
     # enough for thousands of hand-overs between the waves, continued twice (the step counter carries on), with
-    # traces; and the same chains from the plain form and from two waves per chain: bit for bit the same in every read-back
+    # traces; and the same chains from the plain form and from two and three waves per chain: bit for bit the same in every read-back
     from mcmc_amd.scene import make_scene
     sc = make_scene(seed=1)
     S = sc.n_superpixels
@@ -251,13 +251,13 @@ def test_chain_parity_speculative_form_long_run(gpu_ctx_factory):
     ctx.chains_set_trace(3000)
     for burn, iters in ((500, 2500), (0, 1500), (0, 7)):
         ctx.chains_run(burn, iters)
-        assert ctx.last_variant() == 144
+        assert ctx.last_variant() == 244
         st, tr = orc.run(burn, iters, trace=True)
         assert st == 0 and np.array_equal(ctx.trace(), tr)
         _compare_chains(ctx, orc)
         assert np.array_equal(ctx.marginals(0)[:S], orc.marginals())
     spec = ctx.scalars()
-    for opt, variant in ((-1, 14), (2, 44)):
+    for opt, variant in ((-1, 14), (2, 44), (3, 144)):
         ctx.set_option("k3_spec", opt)
         ctx.chains_init(n, chains_per_frame=n, seed=8)
         for burn, iters in ((500, 2500), (0, 1500), (0, 7)):
