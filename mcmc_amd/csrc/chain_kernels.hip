@@ -130,14 +130,13 @@ MC_D uint32_t wave_scan_max_u32(uint32_t v)
     return v;
 }
 
-// idx-th set flag (ascending) of a byte-flag array read as NWB 32-bit words (4 flags each,
-// every flag 0 or 1); wave-uniform result = the flag's index
-MC_D uint32_t nth_flag(const uint32_t* words, int NWB, uint32_t idx, int lane)
+// idx-th set bit (ascending) of a bit set of NW 32-bit words; wave-uniform result = the bit's index
+MC_D uint32_t nth_flag(const uint32_t* words, int NW, uint32_t idx, int lane)
 {
     uint32_t acc = 0, result = 0xFFFFFFFFu;
-    for (int wb = 0; wb < NWB; wb += kWave) {
+    for (int wb = 0; wb < NW; wb += kWave) {
         const int w = wb + lane;
-        const uint32_t word = w < NWB ? words[w] : 0u;
+        const uint32_t word = w < NW ? words[w] : 0u;
         const int pc = __popc(word);
         const int incl = (int)wave_scan_add_u32((uint32_t)pc);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
@@ -148,7 +147,7 @@ MC_D uint32_t nth_flag(const uint32_t* words, int NWB, uint32_t idx, int lane)
             uint32_t ww = word;
             const uint32_t k = here ? rel - excl : 0u;
             for (uint32_t t = 0; t < k; ++t) ww &= ww - 1u;
-            const uint32_t val = (uint32_t)w * 4u + ((uint32_t)(__ffs((int)ww) - 1) >> 3);
+            const uint32_t val = (uint32_t)w * 32u + (uint32_t)(__ffs((int)ww) - 1);
             const uint64_t hm = __ballot(here);
             result = (uint32_t)__builtin_amdgcn_readlane((int)val, __ffsll((unsigned long long)hm) - 1);
             break;
@@ -171,8 +170,8 @@ struct SegFit {
 // ---------------------------------------------------------------------------
 struct LdsLayout {
     size_t fit, q, col, rowp, vlist, sv, chain0, chain_bytes, wave0, wave_bytes, total;
-    size_t c_label, c_scal, c_ctl, c_ring;               // per chain: labels, shared scalars, control words, changed-label ring (SPEC)
-    size_t w_slots, w_cl, w_nflag, w_rbits, w_rpre, w_rng;   // per wave
+    size_t c_label, c_rbits, c_rpre, c_scal, c_ctl, c_ring;   // per chain: labels, root bit set + prefix counts (statistics, used by the committing wave), shared scalars, control words, changed-label ring (SPEC)
+    size_t w_slots, w_cl, w_nflag, w_rng;                // per wave
 };
 constexpr int kRingEntries = 4;    // accepted moves whose changed labels are remembered (a wave is at most three steps ahead)
 constexpr int kSpecScalars = 16;   // 64-bit words of a chain's scalars handed from wave to wave (speculative form)
@@ -203,6 +202,8 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     const size_t NW = (size_t)(S + 31) / 32;
     size_t cb = 0;
     L.c_label = cb; cb += A((size_t)S * 2);
+    L.c_rbits = cb; cb += A(NW * 4);
+    L.c_rpre = cb; cb += A(NW * 4);
     L.c_scal = cb; if (spec) cb += (size_t)kSpecScalars * 8;
     L.c_ctl = cb; if (spec) cb += 16;
     L.c_ring = cb; if (spec) cb += kRingEntries * 4 * 2;
@@ -212,9 +213,7 @@ __host__ __device__ inline LdsLayout make_layout(int S, int E2, int wpb, bool ta
     size_t w = 0;
     L.w_slots = w; if (tab_lds) w += A(queue_slots(S, E2) * 4);
     L.w_cl = w; w += A((size_t)S);
-    L.w_nflag = w; w += A((size_t)S);
-    L.w_rbits = w; w += A(NW * 4);
-    L.w_rpre = w; w += A(NW * 4);
+    L.w_nflag = w; w += A(NW * 4);
     L.w_rng = w; w += 4 * 64 * 4;
     L.wave_bytes = w;
     L.total = o + w * (size_t)wpb * (size_t)(spec ? nspec : 1);
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     // first == rowp[node].  In HBM (tables behind L2) a slot is .x = node | entries << 16 (4 bits) | part << 20
     // (12 bits), .y = first CSR entry.
     uint32_t* slots32 = reinterpret_cast<uint32_t*>(wbase + L.w_slots);
-    uint2* slots64 = reinterpret_cast<uint2*>(a.slots_g) + ((size_t)chain * NSPEC + role) * queue_slots(s_lds, e2_lds);
+    uint2* slots64 = reinterpret_cast<uint2*>(a.slots_g) + ((size_t)chain * 4 + role) * queue_slots(s_lds, e2_lds);
     auto put_slot = [&](uint32_t idx, uint32_t node, uint32_t first, uint32_t cnt, uint32_t part) __attribute__((always_inline)) {
         if constexpr (TAB_LDS) slots32[idx] = node | (first << 16);
         else slots64[idx] = make_uint2(node | (cnt << 16) | (part << kPartShift), first);
@@ -393,15 +392,17 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     };
     uint8_t* cl = wbase + L.w_cl;                                         // kFree, or in the component
     uint32_t* clw = reinterpret_cast<uint32_t*>(wbase + L.w_cl);
-    uint8_t* nflag = wbase + L.w_nflag;                                   // by label: 1 = neighbouring segment
-    uint32_t* nflagw = reinterpret_cast<uint32_t*>(wbase + L.w_nflag);
-    const int NWB = (int)(((size_t)S + 15) & ~(size_t)15) / 4;            // words of the flag array (zero padded)
-    uint32_t* rbits = reinterpret_cast<uint32_t*>(wbase + L.w_rbits);
-    uint32_t* rpre = reinterpret_cast<uint32_t*>(wbase + L.w_rpre);
+    uint32_t* nflagw = reinterpret_cast<uint32_t*>(wbase + L.w_nflag);    // bit set by label: 1 = neighbouring segment
+    const int NWB = (int)(((size_t)S + 15) & ~(size_t)15) / 4;            // words of the claim bytes (padded)
+    auto nflag_set = [&](uint32_t l) __attribute__((always_inline)) { atomicOr(&nflagw[l >> 5], 1u << (l & 31u)); };
+    auto nflag_get = [&](uint32_t l) -> uint32_t { return (nflagw[l >> 5] >> (l & 31u)) & 1u; };
+    uint32_t* rbits = reinterpret_cast<uint32_t*>(cbase + L.c_rbits);
+    uint32_t* rpre = reinterpret_cast<uint32_t*>(cbase + L.c_rpre);
 
     // per-segment cache, row = the segment's name: 10 exact sums, sum of ssr, probabilityL, member count
     double* g_segC = a.segC + (size_t)chain * a.s_max * kSegCacheStride;
-    for (int w = lane; w < NWB; w += kWave) { clw[w] = 0xFFFFFFFFu; nflagw[w] = 0u; }
+    for (int w = lane; w < NWB; w += kWave) clw[w] = 0xFFFFFFFFu;
+    for (int w = lane; w < NW; w += kWave) nflagw[w] = 0u;
 
     double energy = a.energy[chain], best_energy = a.best_energy[chain];
     uint64_t state_hash = a.state_hash[chain], trace_hash = a.trace_hash[chain];
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
             if constexpr (TAB_LDS) node = slots32[h] & 0xFFFFu; else node = slots64[h].x & 0xFFFFu;
             cl[node] = (uint8_t)kFree;
         }
-        for (int w = lane; w < NWB; w += kWave) nflagw[w] = 0u;
+        for (int w = lane; w < NW; w += kWave) nflagw[w] = 0u;
         wave_fence();
     };
 
@@ -660,8 +661,8 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                         const bool freshA = !(qA < 0.0) && cA == kFree, freshB = !(qB < 0.0) && cB == kFree;
                         const bool joinA = freshA && lA == orig && (rA < qA);
                         const bool joinB = freshB && lB == orig && (rB < qB);
-                        if (freshA && lA != orig) nflag[lA] = 1;
-                        if (freshB && lB != orig) nflag[lB] = 1;
+                        if (freshA && lA != orig) nflag_set(lA);
+                        if (freshB && lB != orig) nflag_set(lB);
                         const uint64_t jmA = __ballot(joinA), jmB = __ballot(joinB);
                         if (jmA | jmB) {
                             // the first claimant of a node in FIFO order wins: tags 64 + lane for A, lane for B, the
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     const bool live = !(qe < 0.0);
                     const bool fresh = live && cj == kFree;
                     const bool join = fresh && lj == orig && (r < qe);   // strict (Segmentation.cpp:110)
-                    if (fresh && lj != orig) nflag[lj] = 1;
+                    if (fresh && lj != orig) nflag_set(lj);
                     const uint64_t jm0 = __ballot(join);
                     if (jm0) {
                         // several lanes may hold an open edge to the same node: the first in FIFO order -- the highest
@@ -796,12 +797,12 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                 if (!same && to_unit(u1_raw) < nsp) { kase = 1; ratio = nsp; }
                 else {
                     int nnl = 0;
-                    for (int w = lane; w < NWB; w += kWave) nnl += __popc(nflagw[w]);
+                    for (int w = lane; w < NW; w += kWave) nnl += __popc(nflagw[w]);
                     const uint32_t numSeg = (uint32_t)wave_sum_i32(nnl) + 1u;
                     const double existing = same ? 1.0 : (1.0 - nsp);
                     const uint32_t idx = idx_draw % numSeg;
                     if (idx == numSeg - 1u) { kase = 0; next = orig; }
-                    else { kase = 2; next = nth_flag(nflagw, NWB, idx, lane); }
+                    else { kase = 2; next = nth_flag(nflagw, NW, idx, lane); }
                     ratio = existing / (double)numSeg;
                 }
 
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
                                     const uint32_t dl = d[c];
-                                    ok = ok && dl != orig && nflag[dl] == 0;
+                                    ok = ok && dl != orig && nflag_get(dl) == 0u;
                                 }
                             }
                         }
@@ -1399,7 +1400,7 @@ size_t chain_run_global_slots(const ChainArgs& a, int s_used_max, int e2_used_ma
         if (a.chains_per_frame % wpbs[wi]) continue;
         if (make_layout(s_used_max, e2_used_max, wpbs[wi], true, true).total <= cap) return 0;
     }
-    return queue_slots(s_used_max, e2_used_max);
+    return 4 * queue_slots(s_used_max, e2_used_max);      // a FIFO per wave, up to four waves per chain
 }
 
 hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max, hipStream_t st, int* variant_out)
@@ -1413,6 +1414,12 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
             const LdsLayout L8 = make_layout(s_used_max, e2_used_max, 8, true, false);
             if (L8.total <= cap && e2_used_max <= 0xFFFF && (a.dense_variant > 0 || a.n_chains > 4 * cus)) {
+                // two waves per chain when their state fits as well (sixteen waves per CU instead of eight): variant 128
+                const LdsLayout L82 = make_layout(s_used_max, e2_used_max, 8, true, false, false, 2);
+                if (L82.total <= cap && a.spec_variant >= 0 && a.burn_in + a.iters < 0x7FFFFFFFull) {
+                    if (variant_out) *variant_out = 128;
+                    return launch_variant<8, true, false, false, false, 2>(a, s_used_max, e2_used_max, L82.total, st);
+                }
                 if (variant_out) *variant_out = 28;
                 return launch_variant<8, true, false>(a, s_used_max, e2_used_max, L8.total, st);
             }
@@ -1445,6 +1452,37 @@ hipError_t launch_chain_run(const ChainArgs& a, int s_used_max, int e2_used_max,
         if (!tab && a.dense_variant >= 0 && s_used_max <= 0xFFFF) {
             // tables too large for LDS: keep at least the CSR topology there (two of the four dependent round trips
             // of a growth pass), q, records and the FIFO behind L2
+            // ... and, LDS leaving room for one workgroup per CU only, several waves per chain (the speculative form):
+            // as many chains per workgroup as a CU gets (1, 2 or 4), then as many waves per chain as fit, up to four
+            // per SIMD.  Variant 30 + chains per workgroup + 100 * (waves per chain - 2).
+            if (!a.prof && a.spec_variant >= 0 && a.burn_in + a.iters < 0x7FFFFFFFull) {
+                int dev = 0, cus = 0;
+                if (!a.slots_g) return hipErrorInvalidValue;
+                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+                    const int per_cu = (a.n_chains + cus - 1) / cus;
+                    int wpb = per_cu <= 1 ? 1 : (per_cu <= 2 ? 2 : 4);
+                    while (wpb > 1 && a.chains_per_frame % wpb) wpb >>= 1;
+                    const int want = a.spec_variant >= 2 ? min(a.spec_variant, 4) : 4;
+                    for (int ns = min(want, 16 / wpb); ns >= 2; --ns) {
+                        const LdsLayout L = make_layout(s_used_max, e2_used_max, wpb, false, false, true, ns);
+                        if (L.total > cap) continue;
+                        if (variant_out) *variant_out = 30 + wpb + 100 * (ns - 2);
+                        if (wpb == 4) {
+                            if (ns == 4) return launch_variant<4, false, false, false, true, 4>(a, s_used_max, e2_used_max, L.total, st);
+                            if (ns == 3) return launch_variant<4, false, false, false, true, 3>(a, s_used_max, e2_used_max, L.total, st);
+                            return launch_variant<4, false, false, false, true, 2>(a, s_used_max, e2_used_max, L.total, st);
+                        }
+                        if (wpb == 2) {
+                            if (ns == 4) return launch_variant<2, false, false, false, true, 4>(a, s_used_max, e2_used_max, L.total, st);
+                            if (ns == 3) return launch_variant<2, false, false, false, true, 3>(a, s_used_max, e2_used_max, L.total, st);
+                            return launch_variant<2, false, false, false, true, 2>(a, s_used_max, e2_used_max, L.total, st);
+                        }
+                        if (ns == 4) return launch_variant<1, false, false, false, true, 4>(a, s_used_max, e2_used_max, L.total, st);
+                        if (ns == 3) return launch_variant<1, false, false, false, true, 3>(a, s_used_max, e2_used_max, L.total, st);
+                        return launch_variant<1, false, false, false, true, 2>(a, s_used_max, e2_used_max, L.total, st);
+                    }
+                }
+            }
             for (int wi = 0; wi < 3; ++wi) {
                 const int wpb = wpbs[wi];
                 if (a.chains_per_frame % wpb) continue;

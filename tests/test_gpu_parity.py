@@ -207,7 +207,7 @@ def test_chain_parity_small(scene_c2_small, gpu_ctx_factory):
     assert np.array_equal(ctx.marginals(0)[:sc.n_superpixels], orc.marginals())
 
 
-@pytest.mark.parametrize("dense,spec,variant", [(1, -1, 28), (-1, -1, 14), (-1, 0, 244), (-1, 1, 244), (-1, 2, 44), (-1, 3, 144),
+@pytest.mark.parametrize("dense,spec,variant", [(1, -1, 28), (1, 0, 128), (-1, -1, 14), (-1, 0, 244), (-1, 1, 244), (-1, 2, 44), (-1, 3, 144),
                                                 (-1, 4, 244)])
 def test_chain_parity_dense_variant(scene_c2_small, gpu_ctx_factory, dense, spec, variant):
     # eight chains per workgroup with the per-superpixel records read through L2 (picked by itself when the chains
@@ -361,7 +361,7 @@ def test_chain_parity_large_s_global_tables(gpu_ctx_factory, placement):
     ctx.chains_init(6, chains_per_frame=6, seed=3)
     ctx.chains_set_trace(120)
     ctx.chains_run(40, 80)
-    assert ctx.last_variant() // 10 == placement
+    assert ctx.last_variant() % 100 // 10 == placement
     orc = _oracle_chains(sc, 6, seed=3)
     st, tr = orc.run(40, 80, trace=True)
     assert np.array_equal(ctx.trace(), tr)
@@ -408,7 +408,7 @@ def _properties(ctx, S, frames, cpf, burn, iters):
 
 def test_chain_parity_c3_full_size(gpu_ctx_factory):
     # BASELINE config 3 at full size: 1920x1080, ~4500 superpixels, one GPU's share of the 4096 chains (512).
-    # The tables (~640 KB) do not fit LDS: placement 3 (CSR topology in LDS, the rest behind L2).
+    # The tables (~640 KB) do not fit LDS: placement 3 (CSR topology in LDS, the rest behind L2), several waves per chain.
     from mcmc_amd.scene import make_scene
     sc = make_scene(width=1920, height=1080, n_planes=24, n_superpixels=4000, seed=2)
     S = sc.n_superpixels
@@ -421,7 +421,7 @@ def test_chain_parity_c3_full_size(gpu_ctx_factory):
     ctx.chains_init(4, seed=2)
     ctx.chains_set_trace(100)
     ctx.chains_run(30, 70)
-    assert ctx.last_variant() // 10 == 3
+    assert ctx.last_variant() % 100 // 10 == 3
     orc = _oracle_chains(sc, 4, seed=2)
     st, tr = orc.run(30, 70, trace=True)
     assert st == 0 and np.array_equal(ctx.trace(), tr)
@@ -431,7 +431,8 @@ def test_chain_parity_c3_full_size(gpu_ctx_factory):
     # first three against the oracle run with the same global ids
     ctx.chains_init(512, seed=2, chain_offset=1024)
     ctx.chains_run(50, 150)
-    assert ctx.last_variant() // 10 == 3
+    # two chains per CU: the speculative form with two chains per workgroup and four waves per chain (variant 232)
+    assert ctx.last_variant() == 232
     s = _properties(ctx, [S], 1, 512, 50, 150)
     orc = _oracle_chains(sc, 3, seed=2, off=1024)
     orc.run(50, 150)
@@ -441,7 +442,8 @@ def test_chain_parity_c3_full_size(gpu_ctx_factory):
 
 def test_chain_parity_c5_share_full_size(gpu_ctx_factory):
     # BASELINE config 5, one GPU's share: 32 frames of 640x480 (~500 superpixels), 64 chains each = 2048 chains,
-    # more than four per CU, so eight chains share a workgroup with the records behind L2 (variant 28).
+    # more than four per CU, so eight chains share a workgroup with the records behind L2 (variant 28; 128 with two
+    # waves per chain, which is what fits and runs here).
     from mcmc_amd.scene import make_scene
     F, cpf, burn, iters = 32, 64, 40, 160
     scenes = [make_scene(seed=100 + f) for f in range(F)]
@@ -453,7 +455,7 @@ def test_chain_parity_c5_share_full_size(gpu_ctx_factory):
     ctx.frames_moments(); ctx.frames_edge_probs()
     ctx.chains_init(F * cpf, chains_per_frame=cpf, seed=5)
     ctx.chains_run(burn, iters)
-    assert ctx.last_variant() == 28
+    assert ctx.last_variant() == 128                          # eight chains per workgroup, two waves per chain
     s = _properties(ctx, [sc.n_superpixels for sc in scenes], F, cpf, burn, iters)
     lab = ctx.labels()
     for f in (0, 13, 31):
