@@ -236,6 +236,13 @@ def k1_roofline(host, sc_list, n_frames, reps, device, warm=150):
     m_batch = ctx.moments(n_frames - 1)
     ctx.frames_moments(n_frames - 1, 1)
     assert np.array_equal(m_batch, ctx.moments(n_frames - 1))
+    # the same launch after an idle gap (lower clock, cold caches): the first 25 launches after 2 s without work
+    ctx.synchronize()
+    time.sleep(2.0)
+    cold = []
+    for _ in range(25):
+        ctx.frames_moments()
+        cold.append(ctx.last_kernel_ms(host.K_MOMENTS))
     # the ceiling of this access pattern: same launch shape, loads and waits, arithmetic replaced by an OR
     ctx.set_option("k1_debug", 1)
     sm = []
@@ -257,6 +264,8 @@ def k1_roofline(host, sc_list, n_frames, reps, device, warm=150):
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg, "min_launch_ms": float(np.min(ms)),
             "launches": reps, "warmup_launches": warm, "traffic": traffic,
+            "cold_launch_ms": float(np.mean(cold)), "cold_launch_note": "mean of the first 25 launches after 2 s idle",
+            "cold_frac": alg / (float(np.mean(cold)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stream_only_GBps": alg / (stream_ms * 1e-3) / 1e9, "stream_only_launch_ms": stream_ms,
             "stream_only_note": "the same kernel with the arithmetic replaced by an OR of the words read: what this "
                                 "launch shape and access pattern reach on their own; achieved / stream_only = %.2f"
@@ -298,26 +307,37 @@ def c5_share_line(host, sc_list, device, frames=32, cpf=64, iters=1000, steps=2)
     return out
 
 
-def k3_bound_model(us_per_step):
-    """K3 has no byte stream: a chain step is ~2200 instructions per wave on LDS-resident tables, two waves per chain
-    (the second evaluates the next step speculatively), one chain per SIMD at C2 (1024 chains, 1024 SIMDs).  Its
-    bound is instruction issue of the SIMD: one wave-instruction per 4 cycles (tools/micro/valu_rate.hip: 2.9 - 6
-    cycles by opcode with four waves per SIMD).  Instruction counts are those of profiles/r02_k3_pmc.txt
-    (rocprofv3 --pmc, speculative kernel, launches of 2000 + 500 steps x 1024 chains); the step time is live."""
-    per_chain_step = (3252771178 + 1776047396 + 381801841 + 63634526) * 2 / (1024.0 * 2500.0)   # VALU + SALU + LDS + VMEM
-    model_us = per_chain_step * 4.0 / 2400.0
-    growth_lat = 14.96 * 4 * 65.8                  # passes x dependent LDS round trips x ds_read latency (r02_lds_latency.txt)
-    # the vector pipe alone: its instructions at the 4.8 cycles the f64 / 64-bit-multiply / lane-move mix of this
-    # kernel issues at with two waves per SIMD (profiles/r02_valu_rate_k3.txt); the scalar pipe runs beside it
-    valu_us = 3252771178 * 2 / (1024.0 * 2500.0) * 4.8 / 2400.0
-    return {"kind": "instruction issue per SIMD: instructions per committed chain step x 4 cycles at 2.4 GHz, one chain per SIMD",
-            "instructions_per_chain_step": per_chain_step, "cycles_per_instruction": 4.0, "model_us_per_step": model_us,
-            "achieved_us_per_step": us_per_step, "frac": model_us / us_per_step,
-            "valu_pipe_only_us_per_step": valu_us, "valu_pipe_only_frac": valu_us / us_per_step,
-            "growth_dependent_lds_cycles_per_step": growth_lat,
-            "note": "both waves of a chain, wasted speculation included; the in-order critical path of the growth alone "
-                    "(passes x 4 dependent LDS round trips x 65.8 cycles) is what a single wave per chain could not hide; "
-                    "source of the counts: profiles/r02_k3_pmc.txt, r02_k3_phase_cycles.txt, r02_lds_latency.txt"}
+def k3_bound_model(us_per_step, variant):
+    """K3 has no byte stream: a chain step is ~2400 vector instructions on LDS-resident tables, several waves per chain
+    (the further ones evaluate the next steps speculatively), one chain per SIMD at C2 (1024 chains, 1024 SIMDs).
+    Its bound is the SIMD's vector pipe.  This is a MODEL FROM A RECORDED PROFILE, not a live counter: instruction
+    totals come from profiles/k3_counts.json (tools/prof_k3.sh: rocprofv3 --pmc over tools/k3_profile.py, the same
+    kernel and launch shape), the step time is live; the fractions are only emitted when the kernel variant that ran
+    is the one that was profiled."""
+    path = os.path.join(ROOT, "profiles", "k3_counts.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return {"kind": "no recorded profile (profiles/k3_counts.json missing)", "achieved_us_per_step": us_per_step}
+    t = rec["totals"]
+    per = float(rec["chains"]) * float(rec["steps_per_chain"])
+    valu = t.get("SQ_INSTS_VALU", 0.0) / per
+    others = (t.get("SQ_INSTS_SALU", 0.0) + t.get("SQ_INSTS_LDS", 0.0) + t.get("SQ_INSTS_VMEM_RD", 0.0)) / per
+    # the vector pipe: its instructions at the 4.8 cycles the f64 / 64-bit-multiply / lane-move mix of this kernel issues
+    # at with several waves per SIMD (profiles/r02_valu_rate_k3.txt); scalar, LDS and memory instructions issue beside it
+    valu_us = valu * 4.8 / 2400.0
+    out = {"kind": "model from a recorded profile: vector instructions per committed chain step x 4.8 cycles at 2.4 GHz, one chain per SIMD",
+           "profiled_kernel": rec["kernel"], "profiled_variant": rec.get("variant"), "ran_variant": variant,
+           "valu_instructions_per_chain_step": valu, "other_instructions_per_chain_step": others,
+           "achieved_us_per_step": us_per_step, "source": "profiles/k3_counts.json"}
+    if rec.get("variant") == variant:
+        out["valu_pipe_us_per_step"] = valu_us
+        out["frac"] = valu_us / us_per_step
+        out["note"] = ("frac = vector-pipe time of the recorded instruction count / live step time; all waves of a chain, "
+                       "wasted speculation included")
+    else:
+        out["note"] = "the kernel variant that ran is not the profiled one: no fraction"
+    return out
 
 
 def multiview_line(host, device, n_chains, steps):
@@ -530,12 +550,13 @@ def main():
                        "measured_steps_per_chain": int(total_steps),
                        "note": "Statistics::update visits that found the per-chain visit table full; 0 = every state counted"},
     }
+    ctx_variant = ctx.last_variant()
     if rank == 0:
         out["chain_kernel"] = {"kernel": "chain_run_kernel", "ms_per_launch": k3_ms,
                                "proposals_per_launch": n_local * a.iters_per_step,
                                "us_per_proposal_per_chain": k3_ms * 1e3 / a.iters_per_step,
-                               "bound": "instruction issue (LDS-resident BFS, two waves per chain); not an HBM claim",
-                               "bound_model": k3_bound_model(k3_ms * 1e3 / a.iters_per_step)}
+                               "bound": "vector-pipe issue (LDS-resident BFS, four waves per chain in step order); not an HBM claim",
+                               "bound_model": k3_bound_model(k3_ms * 1e3 / a.iters_per_step, ctx_variant)}
         out["frame_kernels_ms"] = {"sp_moments": ctx.last_kernel_ms(host.K_MOMENTS),
                                    "local_fit": ctx.last_kernel_ms(host.K_LOCAL_FIT),
                                    "edge_prob": ctx.last_kernel_ms(host.K_EDGE_PROB)}

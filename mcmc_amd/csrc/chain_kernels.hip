@@ -173,6 +173,8 @@ struct LdsLayout {
     size_t c_label, c_rbits, c_rpre, c_scal, c_ctl, c_ring;   // per chain: labels, root bit set + prefix counts (statistics, used by the committing wave), shared scalars, control words, changed-label ring (SPEC)
     size_t w_slots, w_cl, w_nflag, w_rng;                // per wave
 };
+// control words of a chain (SPEC): committed and version share an aligned 64-bit word, one LDS read per poll
+constexpr int kCtlFailed = 1, kCtlCommitted = 2, kCtlVersion = 3;
 constexpr int kRingEntries = 4;    // accepted moves whose changed labels are remembered (a wave is at most three steps ahead)
 constexpr int kSpecScalars = 16;   // 64-bit words of a chain's scalars handed from wave to wave (speculative form)
 
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     unsigned char* cbase = smem + L.chain0 + (size_t)cw * L.chain_bytes;
     uint16_t* label = reinterpret_cast<uint16_t*>(cbase + L.c_label);
     unsigned long long* sscal = reinterpret_cast<unsigned long long*>(cbase + L.c_scal);   // SPEC only
-    volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(cbase + L.c_ctl);       // SPEC: next ticket, committed, version, failed
+    volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(cbase + L.c_ctl);       // SPEC: next ticket, failed, committed, version
     // SPEC: the labels an accepted move touched (old segment, target, the two new names), entry (version / 2) % kRingEntries
     volatile uint16_t* ring = reinterpret_cast<volatile uint16_t*>(cbase + L.c_ring);
     uint16_t* g_label = a.label + (size_t)(chain < a.n_chains ? chain : 0) * a.s_max;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                 sscal[12] = 0ull;   // dwell
                 sscal[13] = (unsigned long long)__double_as_longlong(a.last_targetL[chain]);
                 sscal[14] = (unsigned long long)__double_as_longlong(a.last_prop[chain]);
-                ctl[0] = 0u; ctl[1] = 0u; ctl[2] = 0u; ctl[3] = 0u;
+                ctl[0] = 0u; ctl[kCtlCommitted] = 0u; ctl[kCtlVersion] = 0u; ctl[kCtlFailed] = 0u;
             }
         }
     }
@@ -547,6 +549,12 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     };
     // control words, read as wave-uniform scalars
     auto ctl_rd = [&](int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[k]); };
+    // committed count and version in one LDS read
+    auto ctl_poll = [&](uint32_t& committed, uint32_t& version) __attribute__((always_inline)) {
+        const unsigned long long w = *reinterpret_cast<volatile unsigned long long*>(const_cast<uint32_t*>(ctl) + kCtlCommitted);
+        committed = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+        version = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
+    };
     // ~0.1 s of s_sleep polling WITHOUT any step of the chain being committed: far beyond any step (a commit that books
     // visits in a large table included, since the count restarts whenever the chain advances); then the chain is marked failed
     constexpr uint32_t kSpinMax = 1u << 22;
@@ -582,15 +590,15 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
             bool need;
             if constexpr (SPEC) {
                 // a state that is not being rewritten (even version)
-                uint32_t spin = 0, seen = ctl_rd(1);
-                uint32_t cur = ctl_rd(2);
-                while ((cur & 1u) && spin < kSpinMax && ctl_rd(3) == 0u) {
+                uint32_t spin = 0, seen = ctl_rd(kCtlCommitted);
+                uint32_t cur = ctl_rd(kCtlVersion);
+                while ((cur & 1u) && spin < kSpinMax && ctl_rd(kCtlFailed) == 0u) {
                     __builtin_amdgcn_s_sleep(1);
-                    cur = ctl_rd(2);
-                    const uint32_t c1 = ctl_rd(1);
+                    cur = ctl_rd(kCtlVersion);
+                    const uint32_t c1 = ctl_rd(kCtlCommitted);
                     if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
                 }
-                if (cur & 1u) { failed = true; if (lane == 0) ctl[3] = 1u; break; }
+                if (cur & 1u) { failed = true; if (lane == 0) ctl[kCtlFailed] = 1u; break; }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 need = (!evaluated || cur != v0) && (int)(long long)sscal[8] == 0;
                 if (need && evaluated) cleanup();
@@ -948,13 +956,14 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                 // this step's turn, or a change of the state, whichever comes first
                 bool redo = false;
                 for (;;) {
-                    uint32_t spin = 0, seen = ctl_rd(1);
-                    uint32_t cur = ctl_rd(2);
-                    while (seen != (uint32_t)ts && cur == v0 && spin < kSpinMax && ctl_rd(3) == 0u) {
-                        __builtin_amdgcn_s_sleep(1);
-                        const uint32_t c1 = ctl_rd(1);
-                        if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
-                        cur = ctl_rd(2);
+                    uint32_t spin = 0, seen, cur;
+                    ctl_poll(seen, cur);
+                    while (seen != (uint32_t)ts && cur == v0 && spin < kSpinMax) {
+                        __builtin_amdgcn_s_sleep(2);
+                        uint32_t c1;
+                        ctl_poll(c1, cur);
+                        if (c1 != seen) { seen = c1; spin = 0; }
+                        else if ((++spin & 1023u) == 0u && ctl_rd(kCtlFailed) != 0u) break;
                     }
                     if (cur != v0) {
                         // accepted moves since this evaluation (the last one perhaps still being written: its labels
@@ -981,10 +990,10 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     if (seen == (uint32_t)ts) {
                         // every earlier step is committed: nobody else changes the state now
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                        if (ctl_rd(2) == v0) break;
+                        if (ctl_rd(kCtlVersion) == v0) break;
                         continue;                                  // the last commit ahead changed it: look at what it touched
                     }
-                    failed = true; if (lane == 0) ctl[3] = 1u;      // no progress (or another wave gave up)
+                    failed = true; if (lane == 0) ctl[kCtlFailed] = 1u;      // no progress (or another wave gave up)
                     break;
                 }
 #ifdef MC_SPEC_STATS
@@ -1023,10 +1032,10 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                 if constexpr (SPEC) {
                     // what this move touches, then odd: the state is being rewritten
                     if (lane == 0) {
-                        const uint32_t v = ctl[2];
+                        const uint32_t v = ctl[kCtlVersion];
                         volatile uint16_t* d = ring + ((v >> 1) & (uint32_t)(kRingEntries - 1)) * 4u;
                         d[0] = (uint16_t)orig; d[1] = (uint16_t)(kase == 2 ? next : orig); d[2] = (uint16_t)L2; d[3] = (uint16_t)L1;
-                        ctl[2] = v + 1u;
+                        ctl[kCtlVersion] = v + 1u;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 }
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
                     if (have1) g_segC[(size_t)L1 * kSegCacheStride + lane] = v1;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                if constexpr (SPEC) { if (lane == 0) ctl[2] = ctl[2] + 1u; }                                                    // even again: a new state
+                if constexpr (SPEC) { if (lane == 0) ctl[kCtlVersion] = ctl[kCtlVersion] + 1u; }                                                    // even again: a new state
                 energy += targetL;
                 if (energy > best_energy) {
                     best_energy = energy;
@@ -1076,7 +1085,7 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
             // the next step's turn begins before this wave tidies its own scratch
             store_scalars();
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            if (lane == 0) ctl[1] = (uint32_t)ts + 1u;
+            if (lane == 0) ctl[kCtlCommitted] = (uint32_t)ts + 1u;
         }
 #ifdef MC_SPEC_STATS
         st_commit += __builtin_readcyclecounter() - st_c0;
@@ -1093,10 +1102,10 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
     if constexpr (SPEC) {
         // the chain's first wave closes the run once every step is committed
         if (role != 0) return;
-        uint32_t spin = 0, seen = ctl_rd(1);
-        while (seen != (uint32_t)total && spin < kSpinMax && ctl_rd(3) == 0u) {
+        uint32_t spin = 0, seen = ctl_rd(kCtlCommitted);
+        while (seen != (uint32_t)total && spin < kSpinMax && ctl_rd(kCtlFailed) == 0u) {
             __builtin_amdgcn_s_sleep(1);
-            const uint32_t c1 = ctl_rd(1);
+            const uint32_t c1 = ctl_rd(kCtlCommitted);
             if (c1 != seen) { seen = c1; spin = 0; } else ++spin;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

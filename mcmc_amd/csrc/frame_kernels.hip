@@ -214,7 +214,7 @@ MC_D void sums_apply2(uint32_t lab_add, uint32_t lab_sub, uint32_t u0, uint32_t 
     if (sub) {
         unsigned long long* t = tab + (size_t)lab_sub * kMomStride;
 #pragma unroll
-        for (int k = 0; k < kMomStride; ++k) atomicAdd(t + k, 0ull - v[k]);
+        for (int k = 0; k < kMomStride; ++k) __hip_atomic_fetch_sub(t + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ds_sub_u64: no negation
     }
 }
 MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn, int rrn, int rk,
@@ -383,11 +383,6 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     uint32_t* wlog = wbase;
     uint32_t* wq = wbase + kRecCap * kRecDwords;
 
-    if (TABLE_LDS) {
-        for (int i = tid; i < S * kMomStride; i += T) tab[i] = 0ull;
-        __syncthreads();
-    }
-
     const int rows_per_band = (H + a.bands - 1) / a.bands;
     const int r0 = band * rows_per_band;
     const int r1 = min(H, r0 + rows_per_band);
@@ -438,6 +433,11 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     }
 #pragma unroll
     for (int k = 0; k < NSET; ++k) load_row(k, sets[k]);
+    // the table is cleared under the latency of the first loads
+    if (TABLE_LDS) {
+        for (int i = tid; i < S * kMomStride; i += T) tab[i] = 0ull;
+        __syncthreads();
+    }
     uint32_t sink = 0;
     auto row = [&](const int it, RowSet<NQ>& rr) __attribute__((always_inline)) {
         if constexpr (STREAM) {
