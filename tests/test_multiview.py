@@ -313,6 +313,52 @@ def test_gpu_chains_c4_size_bit_exact(gpu_mv):
     assert (own.max(axis=1) < gpu_mv.scalars()["n_segments"]).all()
 
 
+@pytest.mark.gpu
+def test_gpu_chains_c4_all_chains_properties(gpu_mv):
+    """BASELINE configs[3] at the size bench.py runs: 1024 chains x 20 steps.  The oracle is too slow for all of them, so
+    every chain is checked through what the loop must preserve (MultiviewSegmentation.cpp:85-110, 207-257;
+    PatternedMatcher.cpp:58-130) and the first three chains against the oracle bit for bit."""
+    mv = make_multiview(n_views=3, width=640, height=480, n_planes=8, n_superpixels=500, seed=4)
+    _load(gpu_mv, mv)
+    n, steps = 1024, 20
+    gpu_mv.chains_init(n, seed=4, max_new_segments=4 * steps)
+    gpu_mv.chains_set_trace(steps)
+    cur0 = gpu_mv.labels(0).copy()
+    own0 = gpu_mv.labels(1).copy()
+    s0 = gpu_mv.scalars()
+    assert np.array_equal(cur0, own0)                             # before the first step the two labelings agree
+    assert (s0["n_segments"] == cur0.max(axis=1).astype(np.int64) + 1).all()
+    gpu_mv.chains_run(steps)
+    f, a = gpu_mv.trace()
+    s = gpu_mv.scalars()
+    assert f.shape == (n, steps) and (s["status"] == 0).all() and (f != 0xFF).all()
+    # the counters are the trace, summed: accepted, split and skipped proposals
+    assert (s["n_accept"].astype(np.int64) == (f & 1).sum(axis=1)).all()
+    assert (s["n_split"].astype(np.int64) == ((f >> 1) & 1).sum(axis=1)).all()
+    assert (s["n_skip"].astype(np.int64) == ((f >> 2) & 1).sum(axis=1)).all()
+    assert (a[(f & 4) != 0] == 0).all()                           # a skipped proposal has no ratio
+    assert (np.isnan(a) | (a >= 0)).all()
+    # the vertex sets are a partition: every vertex in exactly one segment, ids below the count; every split appended
+    # exactly one segment and it is not empty; currentSegmentID never changes
+    own = gpu_mv.labels(1)
+    assert np.array_equal(gpu_mv.labels(0), cur0)
+    assert (s["n_segments"].astype(np.int64) == s0["n_segments"].astype(np.int64) + s["n_split"].astype(np.int64)).all()
+    assert (own.max(axis=1) < s["n_segments"]).all()
+    for k in range(0, n, 97):
+        used = np.unique(own[k])
+        new = used[used >= s0["n_segments"][k]]
+        # a later split may empty an earlier new segment's vertices only by moving them to a newer one
+        assert new.size <= s["n_split"][k] and (new < s["n_segments"][k]).all()
+        assert np.bincount(own[k], minlength=int(s["n_segments"][k])).sum() == mv.n_vertices
+    # the chains differ from one another and the run is deterministic in (seed, chain id)
+    assert np.unique(s["trace_hash"]).size > n // 2
+    orc = O.MvChains(mv, 3, seed=4, max_new_segments=4 * steps)
+    of, oa = orc.run(steps)
+    assert np.array_equal(f[:3], of) and np.array_equal(a[:3].view(np.uint64), oa.view(np.uint64))
+    assert np.array_equal(s["trace_hash"][:3], orc.scalars()["trace_hash"])
+    assert np.array_equal(own[:3], orc.labels(1))
+
+
 # ------------------------------------------------------------------ world graph (SURVEY section 8f row 3)
 def _world_inputs(seed=3, n0=30, n1=25, n2=20, dim=7):
     rng = np.random.default_rng(seed)
