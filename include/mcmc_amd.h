@@ -67,6 +67,10 @@ int mcmc_ctx_destroy(mcmc_ctx *ctx);
 const char *mcmc_last_error(const mcmc_ctx *ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int mcmc_ctx_set_stream(mcmc_ctx *ctx, void *hip_stream);
+/* Waits for the context's stream.  After a mcmc_chains_run it also reports MCMC_E_DEVICE if a chain of the
+ * several-waves-per-chain kernel gave up waiting for its turn (about 0.1 s without any step of that chain being
+ * committed; never observed -- the alternative would be a hang): that chain's status in mcmc_chains_get_scalars
+ * is -2 and it no longer moves; the other chains are unaffected. */
 int mcmc_ctx_synchronize(mcmc_ctx *ctx);
 const char *mcmc_version(void);
 
@@ -109,13 +113,14 @@ int mcmc_frame_get_edge_probs(mcmc_ctx *ctx, int frame, double *q /* e2; -1 = ed
 int mcmc_segment_probability(mcmc_ctx *ctx, int frame, const uint32_t *members, int n_members,
                              double *probL, double *theta3, double *err);
 
-/* No counterpart in the reference.  mcmc_segment_probability for callers that cannot allocate device memory (code
- * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same result bit
- * for bit, but the membership bytes, the member list and the result are staged in a static device array of the
- * library (328 KB per GPU, held until the process ends) instead of buffers the context allocates, and the call
- * makes no hipMalloc / hipFree.  Limits: n_members <= 65536 and at most 65536 superpixels, else MCMC_E_TOO_LARGE.
- * Every context on one GPU shares that GPU's array: calls that overlap on one GPU (two host threads, two
- * contexts) race; calls one after the other are safe, each clears what it needs. */
+/* No counterpart in the reference.  mcmc_segment_probability for callers that cannot allocate device memory (tight
+ * serving loops, harnesses that forbid hipMalloc): same arguments, same result bit for bit, but the membership
+ * bytes, the member list and the result are staged in a static device array of the library (328 KB per GPU, held
+ * until the process ends) instead of buffers the context allocates, and the call makes no hipMalloc / hipFree.
+ * It is NOT capturable into a HIP graph: it copies the member list from the caller's (pageable) host memory, copies
+ * the result back and synchronises the stream before it returns.  Limits: n_members <= 65536 and at most 65536
+ * superpixels, else MCMC_E_TOO_LARGE.  Every context on one GPU shares that GPU's array: calls that overlap on one
+ * GPU (two host threads, two contexts) race; calls one after the other are safe, each clears what it needs. */
 int mcmc_segment_probability_noalloc(mcmc_ctx *ctx, int frame, const uint32_t *members, int n_members,
                                      double *probL, double *theta3, double *err);
 

@@ -55,6 +55,8 @@ struct Chains {
     unsigned long long measured = 0;       // Statistics::update calls made so far per chain (steps after burn-in)
     unsigned long long occ_known = 0, since_known = 0;   // largest table occupancy when last read; measured steps since
     unsigned int* d_occ = nullptr;
+    unsigned int* d_fault = nullptr;       // set by the chain kernel when a chain gives up a wait (status -2)
+    bool fault_unread = false;             // a run was launched since d_fault was last read
 };
 
 constexpr int kVisitCapAuto0 = 512;        // first size of an automatically sized visit table
@@ -129,7 +131,7 @@ void free_chains(Chains& h)
     dfree(h.segC); dfree(h.energy); dfree(h.best_energy); dfree(h.tmp_energy);
     dfree(h.state_hash); dfree(h.trace_hash); dfree(h.n_accept); dfree(h.n_case);
     dfree(h.visit_hash); dfree(h.visit_count); dfree(h.overflow); dfree(h.top_count); dfree(h.top_hash);
-    dfree(h.status); dfree(h.trace); dfree(h.slots_g); dfree(h.last_targetL); dfree(h.last_prop); dfree(h.best_rec); dfree(h.d_occ);
+    dfree(h.status); dfree(h.trace); dfree(h.slots_g); dfree(h.last_targetL); dfree(h.last_prop); dfree(h.best_rec); dfree(h.d_occ); dfree(h.d_fault);
     h = Chains();
 }
 
@@ -160,7 +162,7 @@ ChainArgs chain_args(mcmc_ctx* c)
     a.energy = c->ch.energy; a.best_energy = c->ch.best_energy;
     a.best_label = c->ch.best_label; a.top_label = c->ch.top_label;
     a.state_hash = c->ch.state_hash; a.trace_hash = c->ch.trace_hash;
-    a.n_accept = c->ch.n_accept; a.n_case = c->ch.n_case; a.status = c->ch.status;
+    a.n_accept = c->ch.n_accept; a.n_case = c->ch.n_case; a.status = c->ch.status; a.fault = c->ch.d_fault;
     a.visit_hash = c->ch.visit_hash; a.visit_count = c->ch.visit_count;
     a.overflow = c->ch.overflow; a.top_count = c->ch.top_count; a.top_hash = c->ch.top_hash;
     a.last_targetL = c->ch.last_targetL; a.last_prop = c->ch.last_prop;
@@ -301,6 +303,17 @@ int mcmc_ctx_synchronize(mcmc_ctx* c)
     if (!c) return MCMC_E_BADARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // a chain that gave up waiting for its turn (speculative forms; never seen) has status -2 in get_scalars: say so here,
+    // where the caller learns that the run is over
+    if (c->ch.n && c->ch.fault_unread && c->ch.d_fault) {
+        unsigned int f = 0;
+        HIPCHK(c, hipMemcpy(&f, c->ch.d_fault, sizeof f, hipMemcpyDeviceToHost));
+        c->ch.fault_unread = false;
+        if (f) {
+            HIPCHK(c, hipMemset(c->ch.d_fault, 0, sizeof f));
+            return fail(c, MCMC_E_DEVICE, "chains_run: a chain's wait for its turn ran out; its status in mcmc_chains_get_scalars is -2 and it no longer moves");
+        }
+    }
     return MCMC_OK;
 }
 
@@ -639,6 +652,7 @@ int mcmc_chains_init(mcmc_ctx* c, int n_chains, int cpf, uint32_t seed, uint32_t
     HIPCHK(c, dalloc(&h.n_case, N * 3)); HIPCHK(c, dalloc(&h.visit_hash, NH)); HIPCHK(c, dalloc(&h.visit_count, NH));
     HIPCHK(c, dalloc(&h.overflow, N)); HIPCHK(c, dalloc(&h.top_count, N)); HIPCHK(c, dalloc(&h.top_hash, N));
     HIPCHK(c, dalloc(&h.status, N));
+    HIPCHK(c, dalloc(&h.d_fault, 1)); HIPCHK(c, hipMemsetAsync(h.d_fault, 0, sizeof(unsigned int), c->stream));
     HIPCHK(c, dalloc(&h.last_targetL, N)); HIPCHK(c, dalloc(&h.last_prop, N));
     HIPCHK(c, dalloc(&h.best_rec, 2 + ((size_t)c->s_max + 3) / 4));
     HIPCHK(c, hipMemsetAsync(c->d_marg, 0, (size_t)c->n_frames * c->s_max * (size_t)c->p.marginal_bins * 8, c->stream));
@@ -701,6 +715,7 @@ int mcmc_chains_run(mcmc_ctx* c, uint64_t burn_in, uint64_t iters)
         HIPCHK(c, e);
     }
     h.step += total; h.last_steps = total; h.measured += iters; h.since_known += iters;
+    h.fault_unread = true;
     return MCMC_OK;
 }
 

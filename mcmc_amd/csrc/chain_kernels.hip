@@ -1110,7 +1110,10 @@ __global__ __launch_bounds__(WPB * 64 * NSPEC) void chain_run_kernel(ChainArgs a
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         load_scalars();
-        if (failed || seen != (uint32_t)total) status = -2;   // MCMC_E_DEVICE: a wait ran out (never seen; a hang otherwise)
+        if (failed || seen != (uint32_t)total) {              // MCMC_E_DEVICE: a wait ran out (never seen; a hang otherwise)
+            status = -2;
+            if (lane == 0 && a.fault) atomicOr(a.fault, 1u);      // mcmc_ctx_synchronize reports it
+        }
     }
     flush_stats();
     if constexpr (PROF) {

@@ -82,6 +82,7 @@ struct ChainArgs {
     unsigned long long* state_hash; unsigned long long* trace_hash;
     unsigned long long* n_accept; unsigned long long* n_case; // [C][3]
     int* status;
+    unsigned int* fault;       // one word per context: set when a chain ends a run with status -2
     unsigned long long* visit_hash; unsigned long long* visit_count; // [C][hcap]
     unsigned long long* overflow; unsigned long long* top_count; unsigned long long* top_hash;
     double* last_targetL; double* last_prop;   // [C] ratios of the last step (Problem::propose's out-parameters)

@@ -510,18 +510,24 @@ def test_statistics_at_baseline_step_count(gpu_ctx_factory):
     assert ctx.visits()[:2] == orc2.visits()
 
 
-def test_statistics_fixed_capacity_overflow_is_flagged(scene_c2_small, gpu_ctx_factory):
+@pytest.mark.parametrize("spec,variant", [(0, 244), (2, 44), (-1, 14)])
+def test_statistics_fixed_capacity_overflow_is_flagged(scene_c2_small, gpu_ctx_factory, spec, variant):
     # a caller-fixed visit table that fills up: the visits that found no slot are counted exactly as the oracle
-    # counts them, and asking for the most-visited labeling says that it may be wrong
+    # counts them, and asking for the most-visited labeling says that it may be wrong.  In the several-waves-per-chain
+    # kernel the wave that commits walks the full table while the others wait for it: the same counts, status 0, and
+    # mcmc_ctx_synchronize has nothing to report
     from mcmc_amd import host
     sc = scene_c2_small
     ctx = gpu_ctx_factory(width=sc.width, height=sc.height, visit_capacity=5)
     ctx.frames_alloc(1, sc.n_superpixels, sc.col.size)
     _load(ctx, 0, sc)
     ctx.frames_moments(); ctx.frames_edge_probs()
-    ctx.chains_init(6, seed=9)
+    ctx.set_option("k3_spec", spec)
+    ctx.chains_init(8, seed=9)        # a multiple of four: the several-waves forms take whole workgroups
     ctx.chains_run(50, 800)
-    orc = _oracle_chains(sc, 6, seed=9, hcap=5)
+    ctx.synchronize()
+    assert ctx.last_variant() == variant and (ctx.scalars()["status"] == 0).all()
+    orc = _oracle_chains(sc, 8, seed=9, hcap=5)
     orc.run(50, 800)
     gs, os_ = ctx.scalars(), orc.scalars()
     assert gs["overflow"].sum() > 0 and np.array_equal(gs["overflow"], os_["overflow"])
