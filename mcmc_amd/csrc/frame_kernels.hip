@@ -98,9 +98,11 @@ MC_D uint32_t match01(uint32_t lw, uint32_t pat) { return pk_sub_u16_sat(kOnes, 
 // sum r b; only sum b^2 needs 64 bits.  Everything a pixel contributes is a
 // packed 16-bit multiply or a v_dot2 on two pixels per dword, exactly as they sit
 // in HBM.  Replaced accumulators go to a per-wave LDS log with plain 16-byte
-// stores; the log is applied 32 records at a time, one record per lane, which is
-// where strip-local sums become the int64 frame moments (10 ds_add_u64 per
-// record into the workgroup's table).
+// stores; the log is applied up to 64 records at a time (kRecCap), one record per
+// lane, which is where strip-local sums become the int64 frame moments: the
+// accumulators keep RUNNING sums, so a record is added to the label it leaves
+// (10 ds_add_u64 into the workgroup's table) and subtracted from the label it
+// takes up (10 ds_sub_u64); the records that close a strip are added only.
 // ---------------------------------------------------------------------------
 constexpr int kRecCap = 64;        // records per wave log (one eviction per lane always fits)
 constexpr int kRecDwords = 12;     // 48 B per record
@@ -403,11 +405,11 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
 
     // NSET register sets hold the rows it .. it+NSET-1 of the strip (three: with non-temporal loads two to three rows in
     // flight measured 1.5 % faster than four, five and six slower; tools/ab).  The loads are issued by hand and
-    // waited for with counted s_waitcnt (in-order return): a set is reloaded with row it+4 as soon as its
+    // waited for with counted s_waitcnt (in-order return): a set is reloaded with row it+NSET as soon as its
     // words have been consumed, and a row only waits until all but the younger loads have landed,
     // so 4-6 KB (NQ = 1) or 8-12 KB (NQ = 2) per wave stay in flight under the arithmetic.  Every load is issued
-    // by every wave (row index clamped per lane; the last reloads re-read the strip's last row), otherwise the
-    // count of younger loads would not be the constant the wait relies on.
+    // by every wave (rows past the strip's end read the frame's first row at the lane's column, which stays in the
+    // cache), otherwise the count of younger loads would not be the constant the wait relies on.
     const int cl = max(count, 1);
     const int pitch = G * 16 * NQ;                                             // bytes per row of a plane
     const uint32_t safe0 = (uint32_t)(min(rs, H - 1) * pitch + g * 16 * NQ);   // byte offset, < 2^25 per frame
