@@ -530,53 +530,82 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             };
             uint32_t head = 0, tail = 1;
             stamp(1);
+            // coarse timers of wave 0 (option "profile"): a handful of clock reads per level and per batch of trials -- a
+            // clock read is a scalar-memory round trip, so nothing shorter than that is bracketed
+            const bool gp = MODE == 1 && a.prof != nullptr;
+            unsigned long long g_scan = 0, g_batch = 0, g_last = 0, g_bar = 0, g_nb = 0, g_trips = 0;
+            const unsigned long long tg0 = gp ? __builtin_readcyclecounter() : 0ull;
             while (head < tail) {
                 if (MODE == 1 && a.prof && tid == 0) atomicAdd(a.prof + 8, 1ull);
+                const unsigned long long tl0 = gp ? __builtin_readcyclecounter() : 0ull;
                 uint32_t cn = 0;
-                // a wave's frontier vertices in turn; the row of the next one is fetched under the scan of the current one
-                uint32_t vi = head + (uint32_t)wave;
-                unsigned long long aw = 0ull, naw = 0ull;
-                uint32_t wb = 0u, nwb = 0u;
-                auto fetch = [&](uint32_t at, unsigned long long& ra, uint32_t& rb) {
-                    const size_t r = (size_t)uni((uint32_t)L.elist[at]) * (size_t)W64;
-                    ra = 0ull; rb = 0u;
-                    if (lane < W64) { ra = g.abm[r + lane]; rb = g.wbase[r + lane]; }
-                };
-                if (vi < tail) fetch(vi, aw, wb);
-                while (vi < tail) {
-                    const uint32_t vn = vi + (uint32_t)NW;
-                    if (vn < tail) fetch(vn, naw, nwb);
-                    U |= aw;
-                    unsigned long long c = aw & S;
-                    if (c) c &= ~EB[lane];
-                    // one candidate per lane and round: its entry index is the word's first plus the bits below it
-                    for (;;) {
-                        const uint64_t m = __ballot(c != 0ull);
-                        if (m == 0) break;
-                        if (c) {
-                            const int b = __ffsll((unsigned long long)c) - 1;
-                            cb[cn + (uint32_t)mbcnt(m)] = make_uint2(wb + (uint32_t)__popcll(aw & ((1ull << b) - 1ull)), (uint32_t)(lane * 64 + b));
-                            c &= c - 1ull;
-                        }
-                        cn += (uint32_t)__popcll((unsigned long long)m);
-                        wave_lds_fence();
-                        if (cn >= (uint32_t)kWave) {
-                            try_edges(cb[lane], true);
-                            const uint32_t rest = cn - (uint32_t)kWave;
-                            const uint2 keep = (uint32_t)lane < rest ? cb[kWave + lane] : make_uint2(0u, 0u);
-                            wave_lds_fence();
-                            if ((uint32_t)lane < rest) cb[lane] = keep;
-                            cn = rest;
-                            wave_lds_fence();
+                // A wave's frontier vertices in turn, kChunk at a time: the rows of a chunk are all asked for before the first
+                // is scanned, so the wave waits for one round trip per chunk instead of one per vertex.  Every lane loads
+                // every time (vertex and word clamped, masked at the use): a load under a condition is merged with its
+                // "else" value at once, and that merge waits for it.
+#ifndef MC_MV_CHUNK
+#define MC_MV_CHUNK 4
+#endif
+                constexpr int kChunk = MC_MV_CHUNK;
+                const uint32_t lw = (uint32_t)(lane < W64 ? lane : 0);
+                for (uint32_t v0 = head + (uint32_t)wave; v0 < tail; v0 += (uint32_t)(NW * kChunk)) {
+                    unsigned long long ra[kChunk];
+                    uint32_t rb[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        const uint32_t at = min(v0 + (uint32_t)(k * NW), tail - 1u);
+                        const size_t r = (size_t)uni((uint32_t)L.elist[at]) * (size_t)W64 + lw;
+                        ra[k] = g.abm[r]; rb[k] = g.wbase[r];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        if (v0 + (uint32_t)(k * NW) < tail) {      // wave-uniform
+                            const unsigned long long aw = lane < W64 ? ra[k] : 0ull;
+                            const uint32_t wb = rb[k];
+                            U |= aw;
+                            unsigned long long c = aw & S;
+                            if (c) c &= ~EB[lane];
+                            // one candidate per lane and round: its entry index is the word's first plus the bits below it
+                            for (;;) {
+                                const uint64_t m = __ballot(c != 0ull);
+                                if (m == 0) break;
+                                if (c) {
+                                    const int b = __ffsll((unsigned long long)c) - 1;
+                                    cb[cn + (uint32_t)mbcnt(m)] = make_uint2(wb + (uint32_t)__popcll(aw & ((1ull << b) - 1ull)), (uint32_t)(lane * 64 + b));
+                                    c &= c - 1ull;
+                                }
+                                cn += (uint32_t)__popcll((unsigned long long)m);
+                                wave_lds_fence();
+                                if (cn >= (uint32_t)kWave) {
+                                    const unsigned long long tb0 = gp ? __builtin_readcyclecounter() : 0ull;
+                                    try_edges(cb[lane], true);
+                                    if (gp) { g_batch += __builtin_readcyclecounter() - tb0; g_nb++; }
+                                    const uint32_t rest = cn - (uint32_t)kWave;
+                                    const uint2 keep = (uint32_t)lane < rest ? cb[kWave + lane] : make_uint2(0u, 0u);
+                                    wave_lds_fence();
+                                    if ((uint32_t)lane < rest) cb[lane] = keep;
+                                    cn = rest;
+                                    wave_lds_fence();
+                                }
+                            }
+                            if (gp) g_trips++;
                         }
                     }
-                    vi = vn; aw = naw; wb = nwb;
                 }
+                const unsigned long long tl1 = gp ? __builtin_readcyclecounter() : 0ull;
                 if (cn) try_edges(cb[(uint32_t)lane < cn ? lane : 0], (uint32_t)lane < cn);
+                const unsigned long long tl2 = gp ? __builtin_readcyclecounter() : 0ull;
                 __syncthreads();
                 head = tail; tail = uni(sh->nE);
                 __syncthreads();
+                if (gp) { g_scan += tl1 - tl0; g_last += tl2 - tl1; g_bar += __builtin_readcyclecounter() - tl2; }
             }
+            if (gp && tid == 0) {
+                const unsigned long long tot = __builtin_readcyclecounter() - tg0;
+                atomicAdd(a.prof + 24, g_scan); atomicAdd(a.prof + 25, g_batch); atomicAdd(a.prof + 26, g_last); atomicAdd(a.prof + 27, g_bar);
+                atomicAdd(a.prof + 28, g_nb); atomicAdd(a.prof + 29, g_trips); atomicAdd(a.prof + 30, tot); atomicMax(a.prof + 31, tot);
+            }
+
             // the neighbours of the grown set, all waves together (read by wave 0 after the next barrier)
             if (U & ~S) atomicOr(&NBU[lane], U & ~S);
             stamp(2);

@@ -26,6 +26,9 @@ if os.environ.get("PHASES"):
     for k, nm in enumerate(names):
         print(f"{nm:16s} {p[k] / n:10.0f} cycles per chain-step")
     print(f"levels {p[8] / n:.1f}  grown vertices {p[9] / n:.1f}")
+    print(f"growth, wave 0 (coarse timers): whole loop {p[30] / n:.0f} cycles per chain-step (slowest chain-step {p[31]:.0f}); scanning the frontier "
+          f"{(p[24] - p[25]) / n:.0f} for {p[29] / n:.1f} trips, {p[28] / n:.1f} full batches of trials {p[25] / n:.0f}, "
+          f"the level's last batch {p[26] / n:.0f}, level barriers {p[27] / n:.0f}")
     st = float(os.environ.get("STEPS", 10))
     if p[19]:
         print(f"L1 kernel per iteration (one item in 16 is timed): items {16 * p[19] / st:.0f}  blocks {16 * p[20] / st:.0f}  matrix instructions {16 * p[21] / st:.0f}  "
