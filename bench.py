@@ -391,7 +391,18 @@ def multiview_line(host, device, n_chains, steps):
         ms4 = m.last_run_ms()
         more = {"chains": 4096, "proposals_per_s": 4096 * steps / (ms4 * 1e-3), "ms_per_launch": ms4}
     m.close()
-    return {"more_chains": more,
+    # the first half of the iteration (component growth + plane fits) has no byte stream and no matrix work: what is
+    # known about its bound comes from recorded experiments, not from a live counter
+    first_half = {"kind": "recorded experiments, not live: profiles/r03_multiview_experiments.txt",
+                  "kernel_us_at_1024_chains": 119.7, "of_which_growth_us": 75.0, "plane_fits_and_hand_over_us": 40.0,
+                  "trial_random_numbers_us": 6.0,
+                  "instructions_per_chain_step": {"valu": 24250, "salu": 14630, "lds": 1745, "vmem": 900},
+                  "wave_cycles_waiting_share": 0.66, "valu_busy_share_per_simd": 0.53,
+                  "one_chain_alone_us": 65.8, "slowest_over_mean_growth": 2.2,
+                  "note": "a one-round launch lasts as long as its slowest chain; 27 % more vector instructions or a third of the "
+                          "row trips left the time unchanged, requesting four rows ahead took 11 us off; dependent global round "
+                          "trips (930 ticks a row, 2500 a 64-lane gather under load) and the tail of the component sizes bound it"}
+    return {"more_chains": more, "first_half_model": first_half,
             "workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
             "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,
