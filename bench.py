@@ -57,8 +57,8 @@ def parse(argv=None):
     ap.add_argument("--iters-per-step", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--roofline-frames", type=int, default=256)
-    ap.add_argument("--roofline-reps", type=int, default=50)
-    ap.add_argument("--roofline-warmup", type=int, default=150)
+    ap.add_argument("--roofline-reps", type=int, default=100)
+    ap.add_argument("--roofline-warmup", type=int, default=400)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -211,7 +211,7 @@ def cpu_baseline_all_cores(sc, seed, seconds, threads):
                       f"measured) steps of the same C2 scene; sum of the threads' measured rates; {cpu_model()}"}
 
 
-def k1_roofline(host, sc_list, n_frames, reps, device, warm=150):
+def k1_roofline(host, sc_list, n_frames, reps, device, warm=400):
     """Moment-accumulation kernel on a batch of frames (C5 shape)."""
     W, H = sc_list[0].width, sc_list[0].height
     smax = max(s.n_superpixels for s in sc_list)
@@ -223,8 +223,9 @@ def k1_roofline(host, sc_list, n_frames, reps, device, warm=150):
         ctx.frame_upload(f, sc.disp, sc.label, sc.n_superpixels)
         alg += W * H * 4 + sc.n_superpixels * 80
     ctx.set_timing(True)
-    # untimed warm-up: a 70 us launch after an idle gap runs at a lower clock; the launch time settles after ~150
-    # launches (tools/ab/k1_warm.py: 72 -> 69 us, and back to 72 after 2 s of idle)
+    # untimed warm-up: a 70 us launch after an idle gap runs at a lower clock; the launch time settles after a few hundred
+    # launches (tools/ab/k1_ab.py: the first 50 after 150 warm-up launches average 68.3 us, the next hundred 67.0; back to
+    # 71-72 after 2 s of idle, which roofline.cold_launch_ms reports beside the steady figure)
     for _ in range(warm):
         ctx.frames_moments()
     ctx.synchronize()

@@ -104,9 +104,15 @@ MC_D uint32_t match01(uint32_t lw, uint32_t pat) { return pk_sub_u16_sat(kOnes, 
 // (10 ds_add_u64 into the workgroup's table) and subtracted from the label it
 // takes up (10 ds_sub_u64); the records that close a strip are added only.
 // ---------------------------------------------------------------------------
-constexpr int kRecCap = 64;        // records per wave log (one eviction per lane always fits)
+#ifndef MC_K1_RECCAP
+#define MC_K1_RECCAP 64
+#endif
+constexpr int kRecCap = MC_K1_RECCAP;        // records per wave log (one eviction per lane always fits)
 constexpr int kRecDwords = 12;     // 48 B per record
 constexpr int kQueueCap = 128;     // queued chunk positions per wave
+// row stride of the moment table in 64-bit words: 10 in HBM; 11 in LDS, where a stride of 10 words puts the same field of
+// all rows on half of the banks (ds_add_u64 on distinct rows: 9.0 cycles per wave-instruction at stride 10, 7.4 at an odd one)
+constexpr int kTabStrideLds = 11;
 constexpr uint32_t kFlushL = 0xFFFEFFFFu, kFlushR = 0xFFFDFFFFu;   // never equal to a 16-bit label; low half 0xFFFF >= S
 
 // Running sums of one accumulator since the START of the strip: they are never restarted.  When the label an
@@ -191,7 +197,7 @@ MC_D void acc_add_row(Acc& s, int cnt, int kr, int br, int r, int r2)
 // (either may be >= S: skipped).  All products are 24-bit or 32x32->64 (u0 < 2^13, vb < 2^12, n <= 1024, strip of
 // <= 128 rows); the table is int64 modulo 2^64, so a subtraction that comes before its addition is harmless.
 MC_D void sums_apply2(uint32_t lab_add, uint32_t lab_sub, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn,
-                      int rrn, int rk, int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S)
+                      int rrn, int rk, int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S, int ts)
 {
     const bool add = lab_add < (uint32_t)S, sub = lab_sub < (uint32_t)S;
     if (!add && !sub) return;
@@ -209,20 +215,20 @@ MC_D void sums_apply2(uint32_t lab_add, uint32_t lab_sub, uint32_t u0, uint32_t 
     v[8] = (unsigned long long)((long long)(int)vb * (long long)b0 + (long long)rb);
     v[9] = ((unsigned long long)bb_hi << 32) | bb_lo;
     if (add) {
-        unsigned long long* t = tab + (size_t)lab_add * kMomStride;
+        unsigned long long* t = tab + (size_t)lab_add * ts;
 #pragma unroll
         for (int k = 0; k < kMomStride; ++k) atomicAdd(t + k, v[k]);
     }
     if (sub) {
-        unsigned long long* t = tab + (size_t)lab_sub * kMomStride;
+        unsigned long long* t = tab + (size_t)lab_sub * ts;
 #pragma unroll
         for (int k = 0; k < kMomStride; ++k) __hip_atomic_fetch_sub(t + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ds_sub_u64: no negation
     }
 }
 MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn, int rrn, int rk,
-                     int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S)
+                     int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S, int ts)
 {
-    sums_apply2(lab, 0xFFFFFFFFu, u0, vb, n, k1, k2, rn, rrn, rk, b0, bk, rb, bb_lo, bb_hi, tab, S);
+    sums_apply2(lab, 0xFFFFFFFFu, u0, vb, n, k1, k2, rn, rrn, rk, b0, bk, rb, bb_lo, bb_hi, tab, S, ts);
 }
 
 MC_D uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -240,24 +246,24 @@ MC_D void rec_write(uint32_t* wlog, int idx, const Acc& s, uint32_t lab_new, uin
     q[2] = lds_u32x4{ (uint32_t)s.rb, s.bb32, 0u, lab_new };
 }
 
-MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int lane)
+MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int ts, int lane)
 {
     const int nact = __popcll((unsigned long long)ballot64(true));
     for (int i = lane; i < cnt; i += nact) {
         const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog, 16)) + i * (kRecDwords / 4);
         const uint4 a = q[0], b = q[1], c = q[2];
         sums_apply2(a.x & 0xFFFFu, c.w, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0x3FFFu), (int)(a.z >> 14),
-                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S);
+                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S, ts);
     }
 }
 
 // append the accumulator of every lane in mask m (pred = this lane's bit); at most one record per lane, so a
 // log of 64 always has room after a drain (wave-uniform control flow)
 MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc& s, uint32_t lab_new, uint32_t u0,
-                     uint32_t vb, unsigned long long* tab, int S, int lane)
+                     uint32_t vb, unsigned long long* tab, int S, int ts, int lane)
 {
     const int k = __popcll((unsigned long long)m);
-    if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, lane); cnt = 0; }
+    if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, ts, lane); cnt = 0; }
     if (pred) rec_write(wlog, cnt + mbcnt(m), s, lab_new, u0, vb);
     cnt += k;
 }
@@ -266,7 +272,7 @@ MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc&
 // right label are added to the table directly (runs of one label merged; normally one run per chunk)
 template <int NQ>
 MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const uint4* lpf, int G,
-                        unsigned long long* tab, int S, int lane)
+                        unsigned long long* tab, int S, int ts, int lane)
 {
     constexpr int NP = 8 * NQ;
     const int nact = __popcll((unsigned long long)ballot64(true));
@@ -295,7 +301,7 @@ MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const ui
             const bool emit = isrest && n != 0 && lab != clab;
             if (ballot64(emit)) {   // a second run of rest pixels in one chunk: rare
                 if (emit) {
-                    sums_apply(clab, g * (uint32_t)NP, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
+                    sums_apply(clab, g * (uint32_t)NP, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S, ts);
                     n = 0; k1 = 0; k2 = 0; b0 = 0; bk = 0; bb = 0;
                 }
             }
@@ -304,7 +310,7 @@ MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const ui
                 bb += (uint64_t)(uint32_t)(b * b);
             }
         }
-        if (n != 0) sums_apply(clab, g * (uint32_t)NP, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S);
+        if (n != 0) sums_apply(clab, g * (uint32_t)NP, row, n, k1, k2, 0, 0, 0, b0, bk, 0, (uint32_t)bb, (uint32_t)(bb >> 32), tab, S, ts);
         // The strip accumulators skipped the squares of this row (they keep them in 32 bits): add sum b^2 of the
         // pixels that match the left or the right label here, one run of equal labels at a time (the pixels that
         // match neither were added with their squares above).
@@ -319,13 +325,13 @@ MC_D void queue_process(const uint32_t* wq, int qcnt, const uint4* dpf, const ui
                 const bool emit = mine && rb2 != 0 && lab != rl;
                 if (ballot64(emit)) {
                     if (emit) {
-                        if (rl < (uint32_t)S) atomicAdd(tab + (size_t)rl * kMomStride + 9, (unsigned long long)rb2);
+                        if (rl < (uint32_t)S) atomicAdd(tab + (size_t)rl * ts + 9, (unsigned long long)rb2);
                         rb2 = 0;
                     }
                 }
                 if (mine) { rl = lab; rb2 += (uint64_t)((int64_t)b * (int64_t)b); }
             }
-            if (rb2 != 0 && rl < (uint32_t)S) atomicAdd(tab + (size_t)rl * kMomStride + 9, (unsigned long long)rb2);
+            if (rb2 != 0 && rl < (uint32_t)S) atomicAdd(tab + (size_t)rl * ts + 9, (unsigned long long)rb2);
         }
     }
 }
@@ -380,7 +386,8 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     const int W = a.W, H = a.H, G = W / NP;
     unsigned long long* gmom = a.mom + (size_t)frame * a.s_max * kMomStride;
     unsigned long long* tab = TABLE_LDS ? lds : gmom;
-    uint32_t* wbase = reinterpret_cast<uint32_t*>(lds + (TABLE_LDS ? (size_t)a.table_rows * kMomStride : 0)) +
+    constexpr int ts = TABLE_LDS ? kTabStrideLds : kMomStride;      // row stride of the table in words
+    uint32_t* wbase = reinterpret_cast<uint32_t*>(lds + (TABLE_LDS ? (size_t)a.table_rows * kTabStrideLds : 0)) +
                       wave * (kRecCap * kRecDwords + kQueueCap);
     uint32_t* wlog = wbase;
     uint32_t* wq = wbase + kRecCap * kRecDwords;
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     for (int k = 0; k < NSET; ++k) load_row(k, sets[k]);
     // the table is cleared under the latency of the first loads
     if (TABLE_LDS) {
-        for (int i = tid; i < S * kMomStride; i += T) tab[i] = 0ull;
+        for (int i = tid; i < S * kTabStrideLds; i += T) tab[i] = 0ull;
         __syncthreads();
     }
     uint32_t sink = 0;
@@ -490,8 +497,8 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
         const uint64_t emL = ballot64(evL);
         const uint64_t emR = ballot64(two) & ballot64(l7 != Rr.lab);   // = ballot64(evR), as two compares and a scalar AND
         if (emL | emR) {     // one branch on the common path
-            if (emL) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, lane);
-            if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, lane);
+            if (emL) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, ts, lane);
+            if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, ts, lane);
         }
         L.lab = l0;
         Rr.lab = evR ? l7 : Rr.lab;
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
         if (rm) {
             // room for this row's chunks (checked here, where the queue is written, not once per row)
             if (__builtin_expect(qcnt + __popcll((unsigned long long)rm) > kQueueCap, 0)) {
-                queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, lane);
+                queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, ts, lane);
                 qcnt = 0;
             }
             if (rest) wq[qcnt + mbcnt(rm)] = (uint32_t)(rs + it) | (squares ? 0u : 0x8000u) | ((uint32_t)g << 16);
@@ -539,22 +546,24 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
         return;
     }
     // flush: queued chunks, both accumulators, the log
-    if (qcnt) queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, lane);
+    if (qcnt) queue_process<NQ>(wq, qcnt, dpf, lpf, G, tab, S, ts, lane);
     {
         // the end of the strip closes both accumulators: their sums go to the label they follow, nothing is subtracted
         const bool wl = L.lab < (uint32_t)S, wr = Rr.lab < (uint32_t)S;
-        rec_append(wlog, cnt, ballot64(wl), wl, L, kFlushL, u0, (uint32_t)rs, tab, S, lane);
-        rec_append(wlog, cnt, ballot64(wr), wr, Rr, kFlushR, u0, (uint32_t)rs, tab, S, lane);
+        rec_append(wlog, cnt, ballot64(wl), wl, L, kFlushL, u0, (uint32_t)rs, tab, S, ts, lane);
+        rec_append(wlog, cnt, ballot64(wr), wr, Rr, kFlushR, u0, (uint32_t)rs, tab, S, ts, lane);
     }
-    rec_drain(wlog, cnt, tab, S, lane);
+    rec_drain(wlog, cnt, tab, S, ts, lane);
 
     if (!TABLE_LDS) return;
     __syncthreads();
+    // LDS rows are kTabStrideLds words apart, HBM rows kMomStride
     if (a.bands == 1) {
-        for (int i = tid; i < S * kMomStride; i += T) gmom[i] = tab[i];
+        for (int i = tid; i < S * kMomStride; i += T) { const int r = i / kMomStride; gmom[i] = tab[i + r * (kTabStrideLds - kMomStride)]; }
     } else {
         for (int i = tid; i < S * kMomStride; i += T) {
-            unsigned long long x = tab[i];
+            const int r = i / kMomStride;
+            unsigned long long x = tab[i + r * (kTabStrideLds - kMomStride)];
             if (x) atomicAdd(gmom + i, x);
         }
     }
@@ -813,7 +822,7 @@ hipError_t launch_moments(const MomentArgs& a, int n_frames, int threads, size_t
 
 size_t moments_lr_lds_bytes(int table_rows, int threads)
 {
-    return (size_t)table_rows * kMomStride * 8 + (size_t)((threads + 63) / 64) * (kRecCap * kRecDwords + kQueueCap) * 4;
+    return (size_t)table_rows * kTabStrideLds * 8 + (size_t)((threads + 63) / 64) * (kRecCap * kRecDwords + kQueueCap) * 4;
 }
 
 hipError_t launch_local_fit(const FitArgs& a, int n_frames, hipStream_t st)
