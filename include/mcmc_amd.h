@@ -287,6 +287,26 @@ long long mcmc_overseg_last_tie_count(mcmc_overseg *os);
  * the device sort and the host scan. */
 int mcmc_overseg_last_sort_ms(mcmc_overseg *os, float *device_sort_ms, float *host_scan_ms);
 
+/* A batch of frames through overSegment (OverSegmentation.cpp:19-54, once per frame; the reference has no batch
+ * form: can05_sampler.cpp:84 handles one frame per process).  The sort and the union-find scan of a frame run on a
+ * host thread, so the batch owns n_workers handles and threads and hands frames out to them; frame f's colours are
+ * colors + f*H*W*3, its disparities disp + f*H*W.  Results of every frame are kept until the next run: the
+ * disparity and label planes on the device (mcmc_overseg_batch_device_buffers -> mcmc_frame_upload_device), the
+ * neighbour CSR on the host.  n_superpixels / n_directed_edges: one entry per frame.  Options as for a single handle
+ * (tie_order).  On an error the first failing frame is named in mcmc_overseg_batch_last_error and no result is kept. */
+typedef struct mcmc_overseg_batch mcmc_overseg_batch;
+int mcmc_overseg_batch_create(int device, int width, int height, int n_workers, mcmc_overseg_batch **out);
+int mcmc_overseg_batch_destroy(mcmc_overseg_batch *b);
+const char *mcmc_overseg_batch_last_error(const mcmc_overseg_batch *b);
+int mcmc_overseg_batch_set_option(mcmc_overseg_batch *b, const char *name, int value);
+int mcmc_overseg_batch_run(mcmc_overseg_batch *b, int n_frames, const uint8_t *colors, const int16_t *disp,
+                           const mcmc_overseg_params *params, int *n_superpixels, uint32_t *n_directed_edges);
+int mcmc_overseg_batch_get_graph(mcmc_overseg_batch *b, int frame, uint32_t *row_ptr /* S+1 */, uint32_t *col /* e2 */);
+int mcmc_overseg_batch_device_buffers(mcmc_overseg_batch *b, int frame, const void **d_disp, const void **d_label);
+int mcmc_overseg_batch_get_labels(mcmc_overseg_batch *b, int frame, uint16_t *out /* H*W */);
+long long mcmc_overseg_batch_tie_count(mcmc_overseg_batch *b, int frame);
+float mcmc_overseg_batch_last_wall_ms(const mcmc_overseg_batch *b);
+
 /* ======================================================================== *
  * Path B: multiview segmentation over an SPGraph (world graph of several
  * views).  Replaces SPGraph / MultiviewSegment / MultiviewSegmentation /

@@ -21,7 +21,10 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -636,5 +639,160 @@ int mcmc_overseg_last_sort_ms(mcmc_overseg* o, float* device_sort_ms, float* hos
     if (host_scan_ms) *host_scan_ms = o->ms_scan;
     return MCMC_OK;
 }
+
+// ---------------------------------------------------------------------------
+// A batch of frames: OverSegmentation::overSegment is per frame and its sort + union-find scan run on a host thread,
+// so a C5-sized job (256 frames) wants one frame per host core.  The batch owns n_workers handles (each with its own
+// stream and buffers) and as many threads; results of every frame are kept until the next run: the device planes in
+// one allocation (they go to mcmc_frame_upload_device as they are), the neighbour CSR on the host.
+// ---------------------------------------------------------------------------
+struct mcmc_overseg_batch {
+    int device = 0, W = 0, H = 0;
+    std::vector<mcmc_overseg*> workers;
+    std::string err;
+    int16_t* d_disp = nullptr; uint16_t* d_label = nullptr; size_t cap_frames = 0;
+    std::vector<std::vector<uint32_t>> rowp, col;
+    std::vector<int> S;
+    std::vector<long long> ties;
+    int n_frames = 0;
+    float wall_ms = 0.f;
+};
+
+namespace {
+int bfail(mcmc_overseg_batch* b, int code, const std::string& msg) { if (b) b->err = msg; return code; }
+}
+
+int mcmc_overseg_batch_create(int device, int width, int height, int n_workers, mcmc_overseg_batch** out)
+{
+    if (!out || n_workers < 1 || n_workers > 64) return MCMC_E_BADARG;
+    *out = nullptr;
+    mcmc_overseg_batch* b = new mcmc_overseg_batch();
+    b->device = device; b->W = width; b->H = height;
+    for (int k = 0; k < n_workers; ++k) {
+        mcmc_overseg* w = nullptr;
+        const int rc = mcmc_overseg_create(device, width, height, &w);
+        if (rc != MCMC_OK) { for (mcmc_overseg* x : b->workers) mcmc_overseg_destroy(x); delete b; return rc; }
+        b->workers.push_back(w);
+    }
+    *out = b;
+    return MCMC_OK;
+}
+
+int mcmc_overseg_batch_destroy(mcmc_overseg_batch* b)
+{
+    if (!b) return MCMC_E_BADARG;
+    (void)hipSetDevice(b->device);
+    for (mcmc_overseg* w : b->workers) mcmc_overseg_destroy(w);
+    ofree(b->d_disp); ofree(b->d_label);
+    delete b;
+    return MCMC_OK;
+}
+
+const char* mcmc_overseg_batch_last_error(const mcmc_overseg_batch* b) { return b ? b->err.c_str() : "null handle"; }
+
+int mcmc_overseg_batch_set_option(mcmc_overseg_batch* b, const char* name, int value)
+{
+    if (!b) return MCMC_E_BADARG;
+    for (mcmc_overseg* w : b->workers) {
+        const int rc = mcmc_overseg_set_option(w, name, value);
+        if (rc != MCMC_OK) return bfail(b, rc, mcmc_overseg_last_error(w));
+    }
+    return MCMC_OK;
+}
+
+int mcmc_overseg_batch_run(mcmc_overseg_batch* b, int n_frames, const uint8_t* colors, const int16_t* disp,
+                           const mcmc_overseg_params* p, int* n_superpixels, uint32_t* n_directed_edges)
+{
+    if (!b || n_frames < 1 || !colors || !disp || !p) return bfail(b, MCMC_E_BADARG, "overseg_batch_run: bad argument");
+    if (hipSetDevice(b->device) != hipSuccess) return bfail(b, MCMC_E_DEVICE, "overseg_batch_run: hipSetDevice failed");
+    const size_t N = (size_t)b->W * b->H;
+    b->n_frames = 0;
+    if ((size_t)n_frames > b->cap_frames) {
+        ofree(b->d_disp); ofree(b->d_label); b->cap_frames = 0;
+        if (oalloc(&b->d_disp, N * n_frames) != hipSuccess || oalloc(&b->d_label, N * n_frames) != hipSuccess) {
+            ofree(b->d_disp); ofree(b->d_label);
+            return bfail(b, MCMC_E_DEVICE, "overseg_batch_run: no device memory for the frames' planes");
+        }
+        b->cap_frames = (size_t)n_frames;
+    }
+    b->rowp.assign((size_t)n_frames, {}); b->col.assign((size_t)n_frames, {});
+    b->S.assign((size_t)n_frames, 0); b->ties.assign((size_t)n_frames, 0);
+    std::atomic<int> next(0), failed(0);
+    std::mutex mu;
+    int first_rc = MCMC_OK;
+    std::string first_err;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](mcmc_overseg* w) {
+        (void)hipSetDevice(b->device);
+        for (;;) {
+            const int f = next.fetch_add(1);
+            if (f >= n_frames || failed.load()) return;
+            int S = 0; uint32_t e2 = 0;
+            int rc = mcmc_overseg_run(w, colors + (size_t)f * N * 3, disp + (size_t)f * N, p, &S, &e2);
+            std::string msg = rc == MCMC_OK ? std::string() : std::string(mcmc_overseg_last_error(w));
+            if (rc == MCMC_OK) {
+                b->S[(size_t)f] = S; b->ties[(size_t)f] = w->n_ties;
+                b->rowp[(size_t)f] = w->h_rowp; b->col[(size_t)f] = w->h_col;
+                hipError_t e = hipMemcpyAsync(b->d_disp + (size_t)f * N, w->d_disp, N * 2, hipMemcpyDeviceToDevice, w->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(b->d_label + (size_t)f * N, w->d_label, N * 2, hipMemcpyDeviceToDevice, w->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+                if (e != hipSuccess) { rc = MCMC_E_DEVICE; msg = std::string("overseg_batch_run: ") + hipGetErrorString(e); }
+            }
+            if (rc != MCMC_OK) {
+                std::lock_guard<std::mutex> g(mu);
+                if (first_rc == MCMC_OK) { first_rc = rc; first_err = "frame " + std::to_string(f) + ": " + msg; }
+                failed.store(1);
+                return;
+            }
+        }
+    };
+    const int nt = std::min<int>((int)b->workers.size(), n_frames);
+    std::vector<std::thread> th;
+    for (int k = 1; k < nt; ++k) th.emplace_back(work, b->workers[(size_t)k]);
+    work(b->workers[0]);                       // the calling thread is the first worker
+    for (std::thread& t : th) t.join();
+    b->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (first_rc != MCMC_OK) return bfail(b, first_rc, first_err);
+    b->n_frames = n_frames;
+    for (int f = 0; f < n_frames; ++f) {
+        if (n_superpixels) n_superpixels[f] = b->S[(size_t)f];
+        if (n_directed_edges) n_directed_edges[f] = (uint32_t)b->col[(size_t)f].size();
+    }
+    return MCMC_OK;
+}
+
+int mcmc_overseg_batch_get_graph(mcmc_overseg_batch* b, int frame, uint32_t* row_ptr, uint32_t* col)
+{
+    if (!b || frame < 0 || frame >= b->n_frames) return bfail(b, MCMC_E_STATE, "overseg_batch_get_graph: no such frame in the last run");
+    if (row_ptr) std::memcpy(row_ptr, b->rowp[(size_t)frame].data(), b->rowp[(size_t)frame].size() * 4);
+    if (col) std::memcpy(col, b->col[(size_t)frame].data(), b->col[(size_t)frame].size() * 4);
+    return MCMC_OK;
+}
+
+int mcmc_overseg_batch_device_buffers(mcmc_overseg_batch* b, int frame, const void** d_disp, const void** d_label)
+{
+    if (!b || frame < 0 || frame >= b->n_frames) return bfail(b, MCMC_E_STATE, "overseg_batch_device_buffers: no such frame in the last run");
+    const size_t N = (size_t)b->W * b->H;
+    if (d_disp) *d_disp = b->d_disp + (size_t)frame * N;
+    if (d_label) *d_label = b->d_label + (size_t)frame * N;
+    return MCMC_OK;
+}
+
+int mcmc_overseg_batch_get_labels(mcmc_overseg_batch* b, int frame, uint16_t* out)
+{
+    if (!b || !out || frame < 0 || frame >= b->n_frames) return bfail(b, MCMC_E_STATE, "overseg_batch_get_labels: no such frame in the last run");
+    const size_t N = (size_t)b->W * b->H;
+    if (hipSetDevice(b->device) != hipSuccess || hipMemcpy(out, b->d_label + (size_t)frame * N, N * 2, hipMemcpyDeviceToHost) != hipSuccess)
+        return bfail(b, MCMC_E_DEVICE, "overseg_batch_get_labels: copy failed");
+    return MCMC_OK;
+}
+
+long long mcmc_overseg_batch_tie_count(mcmc_overseg_batch* b, int frame)
+{
+    if (!b || frame < 0 || frame >= b->n_frames) return bfail(b, MCMC_E_STATE, "overseg_batch_tie_count: no such frame in the last run");
+    return b->ties[(size_t)frame];
+}
+
+float mcmc_overseg_batch_last_wall_ms(const mcmc_overseg_batch* b) { return b ? b->wall_ms : -1.f; }
 
 }  // extern "C"

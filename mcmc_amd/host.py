@@ -140,6 +140,16 @@ def load():
         "mcmc_overseg_last_sort_ms": (i, [vp] + [C.POINTER(C.c_float)] * 2),
         "mcmc_overseg_set_option": (i, [vp, C.c_char_p, i]),
         "mcmc_overseg_last_tie_count": (C.c_longlong, [vp]),
+        "mcmc_overseg_batch_create": (i, [i, i, i, i, C.POINTER(vp)]),
+        "mcmc_overseg_batch_destroy": (i, [vp]),
+        "mcmc_overseg_batch_last_error": (C.c_char_p, [vp]),
+        "mcmc_overseg_batch_set_option": (i, [vp, C.c_char_p, i]),
+        "mcmc_overseg_batch_run": (i, [vp, i, vp, vp, C.POINTER(OversegParams), vp, vp]),
+        "mcmc_overseg_batch_get_graph": (i, [vp, i, vp, vp]),
+        "mcmc_overseg_batch_device_buffers": (i, [vp, i, C.POINTER(vp), C.POINTER(vp)]),
+        "mcmc_overseg_batch_get_labels": (i, [vp, i, vp]),
+        "mcmc_overseg_batch_tie_count": (C.c_longlong, [vp, i]),
+        "mcmc_overseg_batch_last_wall_ms": (C.c_float, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -614,3 +624,73 @@ class OverSegmenter:
         """"tie_order": 1 = std::sort on the host, the reference's call (default); 0 = device sort, equal weights in
         creation order (faster; a layout of this library's own wherever weights tie)."""
         self._ck(self.L.mcmc_overseg_set_option(self.h, name.encode(), int(value)))
+
+
+class OverSegmenterBatch:
+    """mcmc_overseg_batch_*: OverSegmentation::overSegment over a batch of frames, n_workers frames at a time (one host
+    thread, stream and set of buffers each); every frame's planes stay on the device, its neighbour graph on the host."""
+
+    def __init__(self, width=640, height=480, n_workers=8, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        self.W, self.H = width, height
+        rc = self.L.mcmc_overseg_batch_create(device, width, height, n_workers, C.byref(self.h))
+        if rc != 0:
+            raise McmcError(rc, "mcmc_overseg_batch_create failed (no GPU?)")
+        self.S = np.zeros(0, np.int32)
+        self.e2 = np.zeros(0, np.uint32)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise McmcError(rc, self.L.mcmc_overseg_batch_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.mcmc_overseg_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        self._ck(self.L.mcmc_overseg_batch_set_option(self.h, name.encode(), int(value)))
+
+    def run(self, colors, disp, params=None):
+        """colors: (F, H, W, 3) uint8 in B, G, R order; disp: (F, H, W) int16.  Returns (S[F], e2[F])."""
+        if params is None:
+            params = OversegParams()
+            self.L.mcmc_overseg_default_params(C.byref(params))
+        colors = np.ascontiguousarray(colors, np.uint8); disp = np.ascontiguousarray(disp, np.int16)
+        F = disp.shape[0]
+        assert colors.shape == (F, self.H, self.W, 3) and disp.shape == (F, self.H, self.W)
+        self.S = np.zeros(F, np.int32); self.e2 = np.zeros(F, np.uint32)
+        self._ck(self.L.mcmc_overseg_batch_run(self.h, F, _ptr(colors, np.uint8), _ptr(disp, np.int16), C.byref(params),
+                                               _ptr(self.S, np.int32), _ptr(self.e2, np.uint32)))
+        return self.S, self.e2
+
+    def graph(self, frame):
+        rp = np.zeros(int(self.S[frame]) + 1, np.uint32); col = np.zeros(int(self.e2[frame]), np.uint32)
+        self._ck(self.L.mcmc_overseg_batch_get_graph(self.h, frame, _ptr(rp, np.uint32), _ptr(col, np.uint32)))
+        return rp, col
+
+    def labels(self, frame):
+        out = np.zeros((self.H, self.W), np.uint16)
+        self._ck(self.L.mcmc_overseg_batch_get_labels(self.h, frame, _ptr(out, np.uint16)))
+        return out
+
+    def device_buffers(self, frame):
+        d = C.c_void_p(); l = C.c_void_p()
+        self._ck(self.L.mcmc_overseg_batch_device_buffers(self.h, frame, C.byref(d), C.byref(l)))
+        return d.value, l.value
+
+    def tie_count(self, frame):
+        n = self.L.mcmc_overseg_batch_tie_count(self.h, frame)
+        if n < 0:
+            self._ck(int(n))
+        return int(n)
+
+    def last_wall_ms(self):
+        return float(self.L.mcmc_overseg_batch_last_wall_ms(self.h))

@@ -317,6 +317,54 @@ def test_gpu_front_end_errors(gpu_os_small):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tie_order", [1, 0])
+def test_gpu_batch_of_frames_equals_frame_by_frame(tie_order):
+    """mcmc_overseg_batch_run (frames handed out to worker threads, each with its own handle and stream) against one
+    handle run frame by frame: same superpixel counts, labels, neighbour graphs and tie counts; the device planes the
+    batch keeps feed mcmc_frame_upload_device directly; a frame that fails is named."""
+    from mcmc_amd import host
+    H, W = 40, 56
+    frames = [_frame(H, W, seed=k) for k in range(7)]             # more frames than workers: a worker takes several
+    disp = np.stack([f[0] for f in frames]); col = np.stack([f[1] for f in frames])
+    single = host.OverSegmenter(W, H, device=0)
+    single.set_option("tie_order", tie_order)
+    p = _params(single, 5, 2.5, 3.0, 120)
+    want = []
+    for k in range(7):
+        S, e2 = single.run(col[k], disp[k], p)
+        want.append((S, e2, single.labels().copy(), single.graph(), single.tie_count()))
+    b = host.OverSegmenterBatch(W, H, n_workers=3, device=0)
+    b.set_option("tie_order", tie_order)
+    for _ in range(2):                                            # a second run reuses the workers and the storage
+        S, e2 = b.run(col, disp, p)
+        for k in range(7):
+            assert (S[k], e2[k]) == want[k][:2]
+            assert np.array_equal(b.labels(k), want[k][2].reshape(H, W))
+            rp, cl = b.graph(k)
+            assert np.array_equal(rp, want[k][3][0]) and np.array_equal(cl, want[k][3][1])
+            assert b.tie_count(k) == want[k][4]
+    assert b.last_wall_ms() > 0
+    # the planes the batch keeps on the device are what the hot path consumes
+    ctx = host.Context(width=W, height=H, device=0)
+    ctx.frames_alloc(7, int(S.max()), int(e2.max()))
+    for k in range(7):
+        d_disp, d_label = b.device_buffers(k)
+        ctx.frame_upload_device(k, d_disp, d_label, int(S[k]))
+        ctx.frame_set_graph(k, *b.graph(k))
+    ctx.frames_moments()
+    for k in (0, 6):
+        assert np.array_equal(ctx.moments(k)[: S[k]], O.moments(disp[k], want[k][2].reshape(H, W), int(S[k])))
+    ctx.close()
+    # an even window whose mean disparity is far from every pixel: "Weird channel value." for that frame
+    with pytest.raises(host.McmcError) as ei:
+        b.run(col, disp, _params(single, 4, 2.5, 3.0, 300))
+    assert ei.value.code == -8 and "frame" in str(ei.value)
+    with pytest.raises(host.McmcError):
+        b.graph(0)                                                # nothing is kept after a failed run
+    b.close(); single.close()
+
+
+@pytest.mark.gpu
 def test_gpu_config1_frame_end_to_end(c1):
     """Config 1: frame -> superpixels -> moments -> edge probabilities -> chains, every stage bit-exact."""
     from mcmc_amd import host

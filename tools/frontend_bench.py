@@ -14,23 +14,22 @@ for _ in range(3):
     S, e2 = o.run(col, disp)
 wall = (time.perf_counter() - t0) / 3 * 1e3
 print("C1: %d superpixels, %d directed edges; stage ms %s; wall %.1f ms per frame" % (S, e2, o.last_ms(), wall))
-# frames are independent: one handle (own stream, own pinned buffers) per host thread; the C call releases the GIL
-import threading
-nthr = int(os.environ.get("THREADS", 8)); per = 4
-hs = [host.OverSegmenter(640, 480) for _ in range(nthr)]
-for h in hs:
-    h.run(col, disp)
-def work(h):
-    for _ in range(per):
-        h.run(col, disp)
-t0 = time.perf_counter()
-th = [threading.Thread(target=work, args=(h,)) for h in hs]
-[t.start() for t in th]; [t.join() for t in th]
-wall_mt = time.perf_counter() - t0
-print("%d host threads, one handle each: %d frames in %.1f ms -> %.2f ms per frame, %.0f frames/s"
-      % (nthr, nthr * per, wall_mt * 1e3, wall_mt * 1e3 / (nthr * per), nthr * per / wall_mt))
-for h in hs:
-    h.close()
+# frames are independent: mcmc_overseg_batch_run hands them out to worker threads, one handle (own stream, own pinned
+# buffers) each; 64 copies of the bundled frame, both tie orders
+nf = int(os.environ.get("FRAMES", 64))
+cols = np.ascontiguousarray(np.broadcast_to(col, (nf,) + col.shape)); disps = np.ascontiguousarray(np.broadcast_to(disp, (nf,) + disp.shape))
+for tie in (1, 0):
+    for nw in [int(x) for x in os.environ.get("WORKERS", "8 16").split()]:
+        b = host.OverSegmenterBatch(640, 480, n_workers=nw)
+        b.set_option("tie_order", tie)
+        b.run(cols[:nw], disps[:nw])
+        t0 = time.perf_counter()
+        Sb, _ = b.run(cols, disps)
+        wall_mt = time.perf_counter() - t0
+        assert (Sb == Sb[0]).all()
+        print("tie_order %d, batch of %d frames on %2d worker threads: %.1f ms -> %.2f ms per frame, %.0f frames/s"
+              % (tie, nf, nw, wall_mt * 1e3, wall_mt * 1e3 / nf, nf / wall_mt), flush=True)
+        b.close()
 ctx = host.Context(width=640, height=480)
 ctx.frames_alloc(1, S, e2)
 d_disp, d_label = o.device_buffers()
