@@ -365,6 +365,25 @@ def test_gpu_batch_of_frames_equals_frame_by_frame(tie_order):
 
 
 @pytest.mark.gpu
+def test_gpu_union_find_against_the_python_transcription_full_frame(c1):
+    """The union-find stage of the PRODUCT (device sort + host scan, tie_order = 0) against the literal Python
+    transcription of segment-graph.h:47-111 / disjoint-set.h:42-79 -- not against the oracle, whose scan is the
+    product's twin -- on the bundled 640x480 frame, where over a hundred thousand edges tie."""
+    from mcmc_amd import host
+    disp, col = c1
+    o = host.OverSegmenter(640, 480, device=0)
+    o.set_option("tie_order", 0)
+    S, _ = o.run(col, disp, o.default_params())
+    assert o.tie_count() > 100000
+    a, b, w = o.edges()                                  # the GPU's edges in creation order (f32 weights)
+    want = _segment_graph_py(640 * 480, a, b, w, 300.0)  # stable order = equal weights in creation order
+    got = o.roots()
+    assert np.array_equal(got, want)
+    assert S == np.unique(want).size
+    o.close()
+
+
+@pytest.mark.gpu
 def test_gpu_config1_frame_end_to_end(c1):
     """Config 1: frame -> superpixels -> moments -> edge probabilities -> chains, every stage bit-exact."""
     from mcmc_amd import host
