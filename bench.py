@@ -264,6 +264,7 @@ def k1_roofline(host, sc_list, n_frames, reps, device, warm=400):
     return {"bound": "hbm", "kernel": "sp_moments_lr_kernel", "workload": f"{n_frames} frames x {W}x{H} (C5 batch)",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg, "min_launch_ms": float(np.min(ms)),
+            "median_launch_ms": float(np.median(ms)), "p90_launch_ms": float(np.percentile(ms, 90)),
             "launches": reps, "warmup_launches": warm, "traffic": traffic,
             "cold_launch_ms": float(np.mean(cold)), "cold_launch_note": "mean of the first 25 launches after 2 s idle",
             "cold_frac": alg / (float(np.mean(cold)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -576,17 +577,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()      # nothing below communicates; the other ranks are done
-    if rank == 0 and world == 1 and cfg == "c2" and not a.no_multiview:
-        out["multiview"] = multiview_line(host, local, a.mv_chains, a.mv_steps)
     if rank == 0:
         c2s = scenes if cfg != "c3" else []
         if (not a.no_roofline or (world == 1 and cfg == "c2" and not a.no_c5)) and len(c2s) < 4:
             c2s = c2s + [make_scene(width=640, height=480, n_planes=8, n_superpixels=500, seed=100 + i)
                          for i in range(4 - len(c2s))]
-        if world == 1 and cfg == "c2" and not a.no_c5:
-            out["c5_share"] = c5_share_line(host, c2s, local)
+        # the roofline kernel first: measured after the secondary lines (which allocate and free gigabytes: 4096 multiview
+        # chains, 2048 C5 chains) a few of its hundred launches take 100+ us (same median, mean 1.5 us higher)
         if not a.no_roofline:
             out["roofline"] = k1_roofline(host, c2s, a.roofline_frames, a.roofline_reps, local, a.roofline_warmup)
+        if world == 1 and cfg == "c2" and not a.no_multiview:
+            out["multiview"] = multiview_line(host, local, a.mv_chains, a.mv_steps)
+        if world == 1 and cfg == "c2" and not a.no_c5:
+            out["c5_share"] = c5_share_line(host, c2s, local)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, seed, a.cpu_seconds)
         if not a.no_cpu_baseline:
