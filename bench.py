@@ -401,9 +401,11 @@ def multiview_line(host, device, n_chains, steps):
                   "instructions_per_chain_step": {"valu": 24250, "salu": 14630, "lds": 1745, "vmem": 900},
                   "wave_cycles_waiting_share": 0.66, "valu_busy_share_per_simd": 0.53,
                   "one_chain_alone_us": 65.8, "slowest_over_mean_growth": 2.2,
-                  "note": "a one-round launch lasts as long as its slowest chain; 27 % more vector instructions or a third of the "
-                          "row trips left the time unchanged, requesting four rows ahead took 11 us off; dependent global round "
-                          "trips (930 ticks a row, 2500 a 64-lane gather under load) and the tail of the component sizes bound it"}
+                  "issue_bound_us": 80.0, "frac_of_issue_bound": 80.0 / 119.7,
+                  "note": "bound: the SIMD's instruction issue over all pipes (42.5 M wave-instructions per launch / 1024 SIMDs x 4.6 "
+                          "cycles = 80 us) and the launch's slowest chain (2.2x the mean growth); moving instructions between pipes "
+                          "(+27 % vector, -9 % scalar) or a third of the row trips left the time unchanged, requesting four rows "
+                          "ahead took 11 us off"}
     return {"more_chains": more, "first_half_model": first_half,
             "workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),

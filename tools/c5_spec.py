@@ -12,7 +12,7 @@ for f in range(32):
     host.load_scene(ctx, f, scs[f % 4])
 ctx.frames_moments(); ctx.frames_edge_probs()
 ctx.set_timing(True)
-for spec, dense in ((0, 0), (1, 0), (-1, 0), (-1, -1)):
+for spec, dense in ((0, 0), (1, -1), (3, -1), (2, -1), (-1, 0), (-1, -1)):
     ctx.set_option("k3_spec", spec); ctx.set_option("k3_dense", dense)
     ctx.chains_init(2048, chains_per_frame=64, seed=5)
     ctx.chains_run(500, 0)
