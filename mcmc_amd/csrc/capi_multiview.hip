@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,11 @@ struct mcmc_mv {
     void* ex_sh = nullptr; uint8_t *ex_inE = nullptr, *ex_need = nullptr; double* ex_err = nullptr;
     uint16_t* ex_plist = nullptr; uint4* ex_queue = nullptr; uint32_t* ex_counters = nullptr;
     int opt_split = -1;   // -1 automatic (split from 32 chains on), 0 fused, 1 split
+    int opt_groups = 0;   // groups of chains, each running its iterations on a stream of its own: 0 automatic, 1..kMaxGroups
+    int ex_groups = 0;    // the group count the exchange buffers were carved for
+    static constexpr int kMaxGroups = 8;
+    hipStream_t gstream[kMaxGroups] = {};
+    hipEvent_t gev_start = nullptr, gev_done[kMaxGroups] = {};
     int opt_prof = 0;
     unsigned long long* d_prof = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
@@ -72,6 +78,7 @@ void free_chains(mcmc_mv* c)
     { uint8_t* p = static_cast<uint8_t*>(c->ex_sh); mvfree(p); c->ex_sh = nullptr; }
     mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err); mvfree(c->d_prof);
     mvfree(c->ex_plist); mvfree(c->ex_queue); mvfree(c->ex_counters);
+    c->ex_groups = 0;
     c->n = 0; c->trace_cap = 0; c->last_steps = 0;
 }
 MvGraph graph_of(const mcmc_mv* c)
@@ -123,6 +130,11 @@ int mcmc_mv_destroy(mcmc_mv* c)
     (void)hipStreamSynchronize(c->stream);
     free_chains(c); free_graph(c); mvfree(c->d_out);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    if (c->gev_start) (void)hipEventDestroy(c->gev_start);
+    for (int k = 0; k < mcmc_mv::kMaxGroups; ++k) {
+        if (c->gev_done[k]) (void)hipEventDestroy(c->gev_done[k]);
+        if (c->gstream[k]) { (void)hipStreamSynchronize(c->gstream[k]); (void)hipStreamDestroy(c->gstream[k]); }
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
     return MCMC_OK;
@@ -382,6 +394,7 @@ int mcmc_mv_set_option(mcmc_mv* c, const char* name, int value)
 {
     if (!c || !name) return MCMC_E_BADARG;
     if (std::string(name) == "split_step") c->opt_split = value;
+    else if (std::string(name) == "groups" && value >= 0 && value <= mcmc_mv::kMaxGroups) c->opt_groups = value;
     else if (std::string(name) == "profile") c->opt_prof = value;
     else return mfail(c, MCMC_E_BADARG, std::string("mv_set_option: unknown option ") + name);
     return MCMC_OK;
@@ -412,15 +425,36 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     // the split iteration (L1 pass on the matrix cores) is the default at every chain count: at C4 it takes 111 us per
     // iteration for one chain against 605 us of the fused kernel (tools/mv_fused.py); "split_step" = 0 keeps the fused one
     const bool split = c->opt_split != 0;
-    if (split && !c->ex_err) {
+    // Groups.  A launch lasts as long as its slowest chain, and the four kernels of an iteration wait for one another;
+    // with the chains in G groups, each running its iterations on a stream of its own, a group only waits for ITS
+    // slowest chain and the groups' kernels fill each other's tails.  Chains do not interact, so the grouping changes no
+    // result.  Each group gets its share of the exchange buffers and sees itself as a whole job (per-chain pointers
+    // advanced to its first chain, chain_offset likewise).  Measured at C4 (tools/mv_groups.py): 4096 chains 6.90 ->
+    // 7.35 M proposals/s with two groups (three the same; from four on the streams outnumber the hardware queues and
+    // it is slower); 1024 chains -- one round of four chains per CU -- gain nothing (5.18 -> 5.16), also not when the
+    // groups are started half an iteration apart.  Automatic: two groups from 2048 chains on.
+    int G = 1;
+    if (split && !c->opt_prof) {
+        G = c->opt_groups > 0 ? c->opt_groups : (c->n >= 2048 ? 2 : 1);
+        G = std::min(G, std::max(1, c->n / 64));
+    }
+    if (split && c->ex_groups != G) {
+        { uint8_t* p8 = static_cast<uint8_t*>(c->ex_sh); mvfree(p8); c->ex_sh = nullptr; }
+        mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err); mvfree(c->ex_plist); mvfree(c->ex_queue); mvfree(c->ex_counters);
         const size_t N = (size_t)c->n, NV = N * c->V;
+        size_t pl = 0, qu = 0;
+        for (int gidx = 0; gidx < G; ++gidx) {
+            const int n0 = (int)((long long)c->n * gidx / G), n1 = (int)((long long)c->n * (gidx + 1) / G);
+            pl += mv_split_plist_entries(c->V, n1 - n0); qu += mv_split_queue_entries(c->V, n1 - n0);
+        }
         uint8_t* shp = nullptr;
         MVCHK(c, mvalloc(&shp, N * mv_exchange_shared_bytes())); c->ex_sh = shp;
         MVCHK(c, mvalloc(&c->ex_inE, NV)); MVCHK(c, mvalloc(&c->ex_need, NV)); MVCHK(c, mvalloc(&c->ex_err, NV * 4));
-        MVCHK(c, mvalloc(&c->ex_plist, mv_split_plist_entries(c->V, c->n))); MVCHK(c, mvalloc(&c->ex_queue, mv_split_queue_entries(c->V, c->n)));
-        MVCHK(c, mvalloc(&c->ex_counters, 2));
-        MVCHK(c, hipMemsetAsync(c->ex_counters, 0, 2 * sizeof(uint32_t), c->stream));
+        MVCHK(c, mvalloc(&c->ex_plist, pl)); MVCHK(c, mvalloc(&c->ex_queue, qu));
+        MVCHK(c, mvalloc(&c->ex_counters, 2 * (size_t)G));
+        MVCHK(c, hipMemsetAsync(c->ex_counters, 0, 2 * (size_t)G * sizeof(uint32_t), c->stream));
         MVCHK(c, hipMemsetAsync(c->ex_need, 0, NV, c->stream));      // all zero between iterations (MvExchange::need)
+        c->ex_groups = G;
     }
     if (c->opt_prof) {
         if (!c->d_prof) MVCHK(c, mvalloc(&c->d_prof, 32));
@@ -428,9 +462,46 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         a.prof = c->d_prof;
     }
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (split) {
+    if (split && G == 1) {
         const MvSplitBufs bufs{ c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->ex_plist, c->ex_queue, c->ex_counters };
         MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, bufs, c->stream));
+    } else if (split) {
+        if (!c->gev_start) MVCHK(c, hipEventCreateWithFlags(&c->gev_start, hipEventDisableTiming));
+        for (int gidx = 0; gidx < G; ++gidx) {
+            if (!c->gstream[gidx]) MVCHK(c, hipStreamCreateWithFlags(&c->gstream[gidx], hipStreamNonBlocking));
+            if (!c->gev_done[gidx]) MVCHK(c, hipEventCreateWithFlags(&c->gev_done[gidx], hipEventDisableTiming));
+        }
+        MVCHK(c, hipEventRecord(c->gev_start, c->stream));
+        MvChainArgs ag[mcmc_mv::kMaxGroups];
+        MvSplitBufs bg[mcmc_mv::kMaxGroups];
+        size_t pl = 0, qu = 0;
+        const size_t V = (size_t)c->V, shb = mv_exchange_shared_bytes();
+        for (int gidx = 0; gidx < G; ++gidx) {
+            const size_t n0 = (size_t)((long long)c->n * gidx / G), n1 = (size_t)((long long)c->n * (gidx + 1) / G);
+            MvChainArgs x = a;
+            x.n_chains = (int)(n1 - n0); x.chain_offset = a.chain_offset + (uint32_t)n0;
+            x.cur += n0 * V; x.own += n0 * V; x.plane += n0 * (size_t)c->seg_cap * 5; x.segP += n0 * (size_t)c->seg_cap;
+            x.segP_valid += n0 * (size_t)c->seg_cap; x.nseg += n0; x.status += n0; x.n_accept += n0; x.n_split += n0;
+            x.n_skip += n0; x.trace_hash += n0;
+            if (x.trace) { x.trace += n0 * a.trace_stride; x.trace_a += n0 * a.trace_stride; }
+            ag[gidx] = x;
+            bg[gidx] = MvSplitBufs{ static_cast<uint8_t*>(c->ex_sh) + n0 * shb, c->ex_inE + n0 * V, c->ex_need + n0 * V,
+                                    c->ex_err + n0 * V * 4, c->ex_plist + pl, c->ex_queue + qu, c->ex_counters + 2 * gidx };
+            pl += mv_split_plist_entries(c->V, (int)(n1 - n0)); qu += mv_split_queue_entries(c->V, (int)(n1 - n0));
+            MVCHK(c, hipStreamWaitEvent(c->gstream[gidx], c->gev_start, 0));
+        }
+        // iteration by iteration across the groups, so that the streams' queues fill side by side
+        for (unsigned long long ts = 0; ts < steps; ++ts) {
+            for (int gidx = 0; gidx < G; ++gidx) {
+                MvChainArgs x = ag[gidx];
+                x.step0 = a.step0 + ts; x.steps = 1; x.trace_first = ts;
+                MVCHK(c, launch_mv_chain_run_split(graph_of(c), x, bg[gidx], c->gstream[gidx]));
+            }
+        }
+        for (int gidx = 0; gidx < G; ++gidx) {
+            MVCHK(c, hipEventRecord(c->gev_done[gidx], c->gstream[gidx]));
+            MVCHK(c, hipStreamWaitEvent(c->stream, c->gev_done[gidx], 0));
+        }
     }
     else MVCHK(c, launch_mv_chain_run(graph_of(c), a, c->stream));
     MVCHK(c, hipEventRecord(c->ev1, c->stream));

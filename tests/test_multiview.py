@@ -282,6 +282,36 @@ def test_gpu_matrix_l1_pass_shapes(gpu_mv, n_chains):
 
 
 @pytest.mark.gpu
+def test_gpu_chain_groups_change_nothing(gpu_mv):
+    """Option "groups": the chains in G groups, each on a stream of its own with its share of the exchange buffers
+    (automatic from 2048 chains on).  Chains do not interact, so every G gives the same chains; 200 chains in three
+    unequal groups, against one group and, for the first chains, the oracle."""
+    mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
+    _load(gpu_mv, mv)
+    gpu_mv.vertex_moments()
+    n, steps = 200, 7
+    got = {}
+    for G in (1, 3, 2):
+        gpu_mv.set_option("groups", G)
+        gpu_mv.chains_init(n, seed=5, chain_offset=9, max_new_segments=16, split_prob=0.2)
+        gpu_mv.chains_set_trace(steps)
+        gpu_mv.chains_run(steps)
+        f, a = gpu_mv.trace()
+        gpu_mv.chains_run(steps)                                  # and a second launch on the same buffers
+        s = gpu_mv.scalars()
+        got[G] = (f.copy(), a.copy(), {k: v.copy() for k, v in s.items()}, gpu_mv.labels(1).copy())
+    gpu_mv.set_option("groups", 0)
+    for G in (3, 2):
+        assert np.array_equal(got[G][0], got[1][0]) and np.array_equal(got[G][1].view(np.uint64), got[1][1].view(np.uint64))
+        for k in got[1][2]:
+            assert np.array_equal(got[G][2][k], got[1][2][k]), (G, k)
+        assert np.array_equal(got[G][3], got[1][3])
+    orc = O.MvChains(mv, 4, seed=5, chain_offset=9, max_new_segments=16, split_prob=0.2)
+    of, oa = orc.run(steps)
+    assert np.array_equal(got[3][0][:4], of) and np.array_equal(got[3][1][:4].view(np.uint64), oa.view(np.uint64))
+
+
+@pytest.mark.gpu
 def test_gpu_chains_capacity_overflow(gpu_mv, mv_small):
     _load(gpu_mv, mv_small)
     gpu_mv.chains_init(2, seed=1, max_new_segments=1, split_prob=1.0)
