@@ -167,7 +167,8 @@ struct MvSplitBufs {
 };
 size_t mv_split_plist_entries(int V, int n_chains);
 size_t mv_split_queue_entries(int V, int n_chains);
-hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a, const MvSplitBufs& bufs, hipStream_t st);
+// split_growth: the first half as two kernels (component growth with more waves per chain, then the plane fits)
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a, const MvSplitBufs& bufs, hipStream_t st, bool split_growth = false);
 size_t mv_exchange_shared_bytes();
 size_t mv_chain_lds_bytes(int V);
 hipError_t launch_mv_world_bits(const float* th, const float* w, int dim, int V, int n0, const uint32_t* in_rowp,

@@ -32,6 +32,10 @@ constexpr int kMvWavesFirstHalf = 4;            // waves per chain in the first 
                                                 // growth time when it has a CU to itself (88 k against 207 k cycles), but with four chains on a CU
                                                 // the iteration takes as long as with four waves (2.25 against 2.15 ms per 10 steps): the CU's
                                                 // throughput, not the chain's latency, is the limit
+#ifndef MC_MV_GROWTH_WAVES
+#define MC_MV_GROWTH_WAVES 8
+#endif
+constexpr int kMvGrowthWaves = MC_MV_GROWTH_WAVES;   // waves per chain of the growth-only kernel (MODE 4)
 constexpr int kMvMaxV = 64 * 64;                // a bitmap row is one 64-bit word per lane (the fused kernel's LDS allows ~3.4 k vertices)
 
 struct Sym33 { double a00, a01, a02, a11, a12, a22; };
@@ -282,19 +286,19 @@ struct MvLds {
 
 // with_err: the [4][V] residual table of the fused kernel (the split halves keep it in HBM, which lets five
 // workgroups share a CU instead of one)
-__host__ __device__ inline size_t mv_lds_bytes(int V, bool with_err)
+__host__ __device__ inline size_t mv_lds_bytes(int V, bool with_err, size_t cand_bytes = kMvCandBytes)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return A(sizeof(MvShared)) + kMvCandBytes + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
+    return A(sizeof(MvShared)) + cand_bytes + (with_err ? A((size_t)V * 32) : 0) + A((size_t)V * 4) + 4 * A((size_t)V * 2) + 2 * A((size_t)V);
 }
 
-MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err)
+MC_D MvLds mv_carve(unsigned char* smem, int V, bool with_err, size_t cand_bytes = kMvCandBytes)
 {
     auto A = [](size_t x) { return (x + 15) & ~(size_t)15; };
     MvLds L;
     size_t o = 0;
     L.sh = reinterpret_cast<MvShared*>(smem + o); o += A(sizeof(MvShared));
-    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += kMvCandBytes;
+    L.cand = reinterpret_cast<uint32_t*>(smem + o); o += cand_bytes;
     L.errv = reinterpret_cast<double*>(smem + o); if (with_err) o += A((size_t)V * 32);
     L.se = reinterpret_cast<uint32_t*>(smem + o); o += A((size_t)V * 4);
     L.cur = reinterpret_cast<uint16_t*>(smem + o); o += A((size_t)V * 2);
@@ -443,7 +447,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = g.V;
-    MvLds L = mv_carve(smem, V, MODE == 0);
+    MvLds L = mv_carve(smem, V, MODE == 0, (size_t)(NW > kMvWaves ? NW : kMvWaves) * 1024);
     MvShared* sh = L.sh;
     const int chain = (int)blockIdx.x;
     // wave index as a scalar: the loops over "this wave's" vertices then get scalar control flow
@@ -460,14 +464,17 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
     unsigned long long* SM = reinterpret_cast<unsigned long long*>(L.sv);   // start's segment as a bitmap, per step
     for (int v = tid; v < V; v += NT) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
     for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
-    if (MODE == 2) {
-        // second half: the grown set, the shared block and the residuals come from the first half and the error kernel
+    if (MODE == 2 || MODE == 3) {
+        // second half (2) / plane fits after a growth kernel (3): the grown set and the shared block come from the kernel
+        // before; the second half also gets the residuals of the error kernel
         for (int v = tid; v < V; v += NT) L.inE[v] = x.inE[(size_t)chain * V + v];
         const uint32_t* src = reinterpret_cast<const uint32_t*>(x.sh + chain);
         uint32_t* dst = reinterpret_cast<uint32_t*>(sh);
         for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
-        L.errv = x.err + (size_t)chain * 4 * V;
-        if (chain == 0 && tid == 0) x.counters[0] = 0u;     // the error kernel has drained the queue: empty for the next iteration
+        if (MODE == 2) {
+            L.errv = x.err + (size_t)chain * 4 * V;
+            if (chain == 0 && tid == 0) x.counters[0] = 0u;     // the error kernel has drained the queue: empty for the next iteration
+        }
     }
     int nseg = a.nseg[chain], status = a.status[chain];
     unsigned long long n_accept = a.n_accept[chain], n_split = a.n_split[chain], n_skip = a.n_skip[chain];
@@ -486,7 +493,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
     for (unsigned long long ts = 0; ts < a.steps; ++ts) {
         const unsigned long long t = a.step0 + ts;
         if (status != 0) {
-            if (MODE != 2 && tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
+            if (MODE != 2 && MODE != 4 && tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
             continue;
         }
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
@@ -497,7 +504,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         // whose trial succeeds whatever the order of the walk: the four waves grow it breadth first, each
         // wave taking frontier vertices in turn, collecting the candidate edges of 64 out-edges at a time and
         // trying them 64 at once (the Philox call is the expensive part; candidates are ~10 % of the edges).
-        if (MODE != 2) {
+        if (MODE != 2 && MODE != 3) {
             const uint32_t start = mv_draw_at(rg, 0u) % (uint32_t)V;
             const uint16_t cs = L.cur[start];
             if (tid == 0) { L.inE[start] = 1; EB[start >> 6] = 1ull << (start & 63u); L.elist[0] = (uint16_t)start; sh->nE = 1u; }
@@ -624,28 +631,38 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         __syncthreads();
         const uint32_t nE = sh->nE, orig = sh->orig;
         int kind = sh->kind;
-        if (kind == 3) {
+        if (kind == 3 && MODE != 4) {
             if (MODE == 2) break;                  // frozen and traced by the first half
             status = -6;
-            for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
-            for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
+            if (MODE != 3) {
+                for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
+                for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
+            }
             if (tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
             __syncthreads();
             continue;
         }
         if (MODE == 2) {
             // nothing: the proposal was made by the first half
-        } else if (kind == 1) {
-            // addNewSegment (MultiviewSegmentation.cpp:85-110): the vertices really move
+        } else if (kind == 1 || kind == 3) {
+            // addNewSegment (MultiviewSegmentation.cpp:85-110): the vertices really move (the growth kernel leaves that
+            // to the kernel that fits the planes, which finds the set in its flags instead of the list)
             const uint32_t tg = sh->target;
-            for (uint32_t i = (uint32_t)tid; i < nE; i += NT) {
-                const uint32_t v = L.elist[i];
-                pvalid[L.own[v]] = 0;
-                L.own[v] = (uint16_t)tg;
+            if (MODE == 3) {
+                for (int v = tid; v < V; v += NT)
+                    if (L.inE[v]) { pvalid[L.own[v]] = 0; L.own[v] = (uint16_t)tg; }
+            } else if (MODE != 4) {
+                for (uint32_t i = (uint32_t)tid; i < nE; i += NT) {
+                    const uint32_t v = L.elist[i];
+                    pvalid[L.own[v]] = 0;
+                    L.own[v] = (uint16_t)tg;
+                }
             }
-            if (tid == 0) pvalid[tg] = 0;
-            nseg++; n_split++;
-        } else {
+            if (MODE != 4) {
+                if (tid == 0) pvalid[tg] = 0;
+                nseg++; n_split++;
+            }
+        } else if (MODE != 3) {
             // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids, from the rows the growth
             // scan has seen (every grown vertex's row exactly once)
             if (wave == 0) {
@@ -689,6 +706,14 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         }
         __syncthreads();
         stamp(3);
+        if (MODE == 4) {
+            // growth kernel done: the set's flags and the shared block go to the kernel that fits the planes
+            for (int v = tid; v < V; v += NT) x.inE[(size_t)chain * V + v] = L.inE[v];
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(x.sh + chain);
+            for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
+            continue;
+        }
         kind = sh->kind;
         const uint32_t target = sh->target;
         if (kind != 2) {
@@ -733,7 +758,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             stamp(4);
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
-            if (MODE == 1) {
+            if (MODE == 1 || MODE == 3) {
                 for (int v = tid; v < V; v += NT) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
@@ -802,7 +827,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             }
             __syncthreads();
             // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
-            if (MODE != 1 && wave < 4 && !sh->have[wave]) {
+            if (MODE != 1 && MODE != 3 && wave < 4 && !sh->have[wave]) {
                 // four rows per trip, fetched whether or not they are members (in the split iteration the table is
                 // behind L2 and a fetch per member would be one round trip after the other); only members are
                 // added, in vertex order
@@ -827,7 +852,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             }
             __syncthreads();
         }
-        if (MODE == 1) {
+        if (MODE == 1 || MODE == 3) {
             // first half done: hand the shared block over (a skipped proposal wants no residuals)
             const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
             uint32_t* dst = reinterpret_cast<uint32_t*>(x.sh + chain);
@@ -858,11 +883,11 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         }
         __syncthreads();
     }
-    if (MODE != 2) for (int v = tid; v < V; v += NT) gown[v] = L.own[v];
+    if (MODE != 2 && MODE != 4) for (int v = tid; v < V; v += NT) gown[v] = L.own[v];
     stamp(6);
     if (tid == 0) {
-        if (MODE != 2) { a.nseg[chain] = nseg; a.status[chain] = status; a.n_split[chain] = n_split; }
-        if (MODE != 1) { a.n_accept[chain] = n_accept; a.n_skip[chain] = n_skip; a.trace_hash[chain] = trace_hash; }
+        if (MODE != 2 && MODE != 4) { a.nseg[chain] = nseg; a.status[chain] = status; a.n_split[chain] = n_split; }
+        if (MODE != 1 && MODE != 3 && MODE != 4) { a.n_accept[chain] = n_accept; a.n_skip[chain] = n_skip; a.trace_hash[chain] = trace_hash; }
     }
 }
 
@@ -1183,6 +1208,12 @@ static hipError_t mv_set_lds_attr()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<4, kMvGrowthWaves>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_init_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
@@ -1232,13 +1263,14 @@ size_t mv_exchange_shared_bytes() { return sizeof(MvShared); }
 size_t mv_split_plist_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * (kErrChainsPerBlock * 4); }
 size_t mv_split_queue_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * kErrItemsPerBlock; }
 
-hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, hipStream_t st)
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, hipStream_t st, bool split_growth)
 {
     if (g.V > kMvMaxV) return hipErrorInvalidValue;
     hipError_t e = mv_set_lds_attr();
     if (e != hipSuccess) return e;
     const size_t bytes = mv_lds_bytes(g.V, false);
-    if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;
+    const size_t gbytes = mv_lds_bytes(g.V, false, (size_t)(kMvGrowthWaves > kMvWaves ? kMvGrowthWaves : kMvWaves) * 1024);
+    if (bytes > 160 * 1024 - 64 || gbytes > 160 * 1024 - 64) return hipErrorInvalidValue;
     MvExchange x{ reinterpret_cast<MvShared*>(bufs.sh), bufs.inE, bufs.need, bufs.err, bufs.plist, bufs.queue, a0.prof, bufs.counters };
     const dim3 pgrid((unsigned)((g.V + kErrVertsPerGroup - 1) / kErrVertsPerGroup), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
     if (pgrid.y > 65535u) return hipErrorInvalidValue;      // > 64 M chains per launch: shard the chains
@@ -1249,7 +1281,12 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
-        hipLaunchKernelGGL((mv_chain_run_kernel<1, kMvWavesFirstHalf>), dim3(a.n_chains), dim3(kMvWavesFirstHalf * 64), bytes, st, g, a, x);
+        if (split_growth) {
+            // the growth in a kernel of its own (eight waves per chain within 64 VGPRs), then the plane fits
+            hipLaunchKernelGGL((mv_chain_run_kernel<4, kMvGrowthWaves>), dim3(a.n_chains), dim3(kMvGrowthWaves * 64), gbytes, st, g, a, x);
+            hipLaunchKernelGGL(mv_chain_run_kernel<3>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+        } else
+            hipLaunchKernelGGL((mv_chain_run_kernel<1, kMvWavesFirstHalf>), dim3(a.n_chains), dim3(kMvWavesFirstHalf * 64), bytes, st, g, a, x);
         hipLaunchKernelGGL(mv_err_pairs_kernel, pgrid, dim3(kErrVertsPerGroup * kWave), 0, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), 0, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);

@@ -7,6 +7,8 @@ mv = make_multiview(n_views=3, width=640, height=480, n_planes=8, n_superpixels=
 m = host.Multiview()
 m.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, mv.q)
 m.vertex_moments()
+if os.environ.get("SPLIT_GROWTH"):
+    m.set_option("split_growth", 1)
 if os.environ.get("FUSED"):
     m.set_option("split_step", 0)
 m.chains_init(int(os.environ.get("CHAINS", 1024)), seed=1)
