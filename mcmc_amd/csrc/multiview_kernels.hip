@@ -438,6 +438,9 @@ struct MvExchange {
 // MODE 1 / MODE 2: the first / second half of ONE iteration; between them mv_errors_kernel evaluates the
 // L1 residuals of all chains vertex by vertex, so a vertex's points are read once for every chain that
 // needs them instead of once per chain.  Same arithmetic in the same order, hence the same bits.
+// MODE 4 + MODE 3: the first half as two kernels -- 4 grows the component and picks the move with NW = kMvGrowthWaves
+// waves per chain inside 64 VGPRs (a chain's latency is what few chains wait for), 3 takes the set's flags and the
+// shared block from it, moves the vertices of a split proposal, fits the planes and writes the chain back.
 // NW: waves per chain (kMvWavesFirstHalf for the first half of a split iteration); the segment fits use waves 0..3
 // whatever NW is.
 template <int MODE, int NW = kMvWaves>
