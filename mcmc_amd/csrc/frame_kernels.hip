@@ -197,7 +197,8 @@ MC_D void acc_add_row(Acc& s, int cnt, int kr, int br, int r, int r2)
 // (either may be >= S: skipped).  All products are 24-bit or 32x32->64 (u0 < 2^13, vb < 2^12, n <= 1024, strip of
 // <= 128 rows); the table is int64 modulo 2^64, so a subtraction that comes before its addition is harmless.
 MC_D void sums_apply2(uint32_t lab_add, uint32_t lab_sub, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn,
-                      int rrn, int rk, int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S, int ts)
+                      int rrn, int rk, int b0, int bk, int rb, uint32_t bb_lo, uint32_t bb_hi, unsigned long long* tab, int S, int ts,
+                      bool rot = false)
 {
     const bool add = lab_add < (uint32_t)S, sub = lab_sub < (uint32_t)S;
     if (!add && !sub) return;
@@ -214,15 +215,31 @@ MC_D void sums_apply2(uint32_t lab_add, uint32_t lab_sub, uint32_t u0, uint32_t 
     v[7] = (unsigned long long)((long long)(int)u0 * (long long)b0 + (long long)bk);
     v[8] = (unsigned long long)((long long)(int)vb * (long long)b0 + (long long)rb);
     v[9] = ((unsigned long long)bb_hi << 32) | bb_lo;
+    // rot (the log's drain: odd lanes): the fields in the order 5..9, 0..4.  Neighbouring records often name the same
+    // two labels -- a boundary that crosses several strips in the same rows -- and neighbouring lanes then do not meet
+    // on one address (same-row collisions cost 2.8 us of a 67 us launch; this takes about half of them away)
+    constexpr int H = kMomStride / 2;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const unsigned long long lo = v[k], hi = v[k + H];
+        v[k] = rot ? hi : lo; v[k + H] = rot ? lo : hi;
+    }
+    const int o0 = rot ? H : 0, o1 = rot ? -H : 0;
     if (add) {
         unsigned long long* t = tab + (size_t)lab_add * ts;
+        unsigned long long *t0 = t + o0, *t1 = t + o1;
 #pragma unroll
-        for (int k = 0; k < kMomStride; ++k) atomicAdd(t + k, v[k]);
+        for (int k = 0; k < H; ++k) atomicAdd(t0 + k, v[k]);
+#pragma unroll
+        for (int k = H; k < kMomStride; ++k) atomicAdd(t1 + k, v[k]);
     }
     if (sub) {
         unsigned long long* t = tab + (size_t)lab_sub * ts;
+        unsigned long long *t0 = t + o0, *t1 = t + o1;
 #pragma unroll
-        for (int k = 0; k < kMomStride; ++k) __hip_atomic_fetch_sub(t + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ds_sub_u64: no negation
+        for (int k = 0; k < H; ++k) __hip_atomic_fetch_sub(t0 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ds_sub_u64: no negation
+#pragma unroll
+        for (int k = H; k < kMomStride; ++k) __hip_atomic_fetch_sub(t1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int k2, int rn, int rrn, int rk,
@@ -253,7 +270,7 @@ MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int 
         const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog, 16)) + i * (kRecDwords / 4);
         const uint4 a = q[0], b = q[1], c = q[2];
         sums_apply2(a.x & 0xFFFFu, c.w, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0x3FFFu), (int)(a.z >> 14),
-                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S, ts);
+                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S, ts, (i & 1) != 0);
     }
 }
 
