@@ -251,37 +251,44 @@ MC_D void sums_apply(uint32_t lab, uint32_t u0, uint32_t vb, int n, int k1, int 
 MC_D uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // record: the label the sums are added to (s.lab), the label they are subtracted from (lab_new), the strip's
-// origin and the running sums
-MC_D void rec_write(uint32_t* wlog, int idx, const Acc& s, uint32_t lab_new, uint32_t u0, uint32_t vb)
+// origin (its column strip g, shifted to bit 17, and its first row vb) and the running sums, in ten dwords: an LDS store
+// costs the CU about 8 cycles per dword whatever the number of lanes that write (tools/micro/lds_sparse_write.hip: two
+// lanes, ds_write_b128 33 cycles, b64 17, b32 8), and two or three lanes write a record on most rows
+MC_D void rec_write(uint32_t* wlog, int idx, const Acc& s, uint32_t lab_new, uint32_t g17, uint32_t vb)
 {
-    // three 16-byte LDS stores (the record stride and the log base are multiples of 16 bytes)
+    // two 16-byte LDS stores and an 8-byte one (the record stride and the log base are multiples of 16 bytes)
     typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4), aligned(16)));
+    typedef uint32_t lds_u32x2 __attribute__((ext_vector_type(2), aligned(8)));
     __attribute__((address_space(3))) lds_u32x4* q =
         (__attribute__((address_space(3))) lds_u32x4*)wlog + idx * (kRecDwords / 4);
-    q[0] = lds_u32x4{ s.lab | (u0 << 16), vb | ((uint32_t)s.n << 16), (uint32_t)s.k1 | ((uint32_t)s.k2 << 14), (uint32_t)s.rn };   // k1 < 2^14, k2 < 2^18
+    // labels are 16 bits (the sentinels' low halves are 0xFFFF >= S); vb < 2^12, n <= 1024; k1 < 2^14, k2 < 2^18; rn < 2^17, g < 2^10
+    q[0] = lds_u32x4{ __builtin_amdgcn_perm(lab_new, s.lab, 0x05040100u), vb | ((uint32_t)s.n << 12),
+                      (uint32_t)s.k1 | ((uint32_t)s.k2 << 14), (uint32_t)s.rn | g17 };
     q[1] = lds_u32x4{ (uint32_t)s.rrn, (uint32_t)s.rk, (uint32_t)s.b0, (uint32_t)s.bk };
-    q[2] = lds_u32x4{ (uint32_t)s.rb, s.bb32, 0u, lab_new };
+    *reinterpret_cast<__attribute__((address_space(3))) lds_u32x2*>(q + 2) = lds_u32x2{ (uint32_t)s.rb, s.bb32 };
 }
 
-MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int ts, int lane)
+MC_D void rec_drain(const uint32_t* wlog, int cnt, unsigned long long* tab, int S, int ts, int lane, int np)
 {
     const int nact = __popcll((unsigned long long)ballot64(true));
     for (int i = lane; i < cnt; i += nact) {
         const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(wlog, 16)) + i * (kRecDwords / 4);
-        const uint4 a = q[0], b = q[1], c = q[2];
-        sums_apply2(a.x & 0xFFFFu, c.w, a.x >> 16, a.y & 0xFFFFu, (int)(a.y >> 16), (int)(a.z & 0x3FFFu), (int)(a.z >> 14),
-                    (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, c.z, tab, S, ts, (i & 1) != 0);
+        const uint4 a = q[0], b = q[1];
+        const uint2 c = *reinterpret_cast<const uint2*>(q + 2);
+        sums_apply2(a.x & 0xFFFFu, a.x >> 16, (a.w >> 17) * (uint32_t)np, a.y & 0xFFFu, (int)(a.y >> 12), (int)(a.z & 0x3FFFu),
+                    (int)(a.z >> 14), (int)(a.w & 0x1FFFFu), (int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)c.x, c.y, 0u, tab, S, ts,
+                    (i & 1) != 0);
     }
 }
 
 // append the accumulator of every lane in mask m (pred = this lane's bit); at most one record per lane, so a
 // log of 64 always has room after a drain (wave-uniform control flow)
-MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc& s, uint32_t lab_new, uint32_t u0,
-                     uint32_t vb, unsigned long long* tab, int S, int ts, int lane)
+MC_D void rec_append(uint32_t* wlog, int& cnt, uint64_t m, bool pred, const Acc& s, uint32_t lab_new, uint32_t g17,
+                     uint32_t vb, unsigned long long* tab, int S, int ts, int lane, int np)
 {
     const int k = __popcll((unsigned long long)m);
-    if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, ts, lane); cnt = 0; }
-    if (pred) rec_write(wlog, cnt + mbcnt(m), s, lab_new, u0, vb);
+    if (__builtin_expect(cnt + k > kRecCap, 0)) { rec_drain(wlog, cnt, tab, S, ts, lane, np); cnt = 0; }
+    if (pred) rec_write(wlog, cnt + mbcnt(m), s, lab_new, g17, vb);
     cnt += k;
 }
 
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     const int R = (max(0, r1 - r0) + nsub - 1) / nsub;       // <= 128 / NQ (host): 32-bit strip-local sums
     const int rs = r0 + p * R, re = min(r1, rs + R);
     const int count = max(0, re - rs);                        // == R for every lane unless RAGGED
-    const uint32_t u0 = (uint32_t)g * (uint32_t)NP;
+    const uint32_t g17 = (uint32_t)g << 17;                         // the strip's column, where a record carries it
     const size_t frame_base = ((size_t)frame * a.frame_stride) / 8;   // in uint4 units (W % 8 == 0)
     const uint4* dpf = reinterpret_cast<const uint4*>(a.disp) + frame_base;
     const uint4* lpf = reinterpret_cast<const uint4*>(a.label) + frame_base;
@@ -514,8 +521,8 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
         const uint64_t emL = ballot64(evL);
         const uint64_t emR = ballot64(two) & ballot64(l7 != Rr.lab);   // = ballot64(evR), as two compares and a scalar AND
         if (emL | emR) {     // one branch on the common path
-            if (emL) rec_append(wlog, cnt, emL, evL, L, l0, u0, (uint32_t)rs, tab, S, ts, lane);
-            if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, u0, (uint32_t)rs, tab, S, ts, lane);
+            if (emL) rec_append(wlog, cnt, emL, evL, L, l0, g17, (uint32_t)rs, tab, S, ts, lane, NP);
+            if (emR) rec_append(wlog, cnt, emR, evR, Rr, l7, g17, (uint32_t)rs, tab, S, ts, lane, NP);
         }
         L.lab = l0;
         Rr.lab = evR ? l7 : Rr.lab;
@@ -567,10 +574,10 @@ __global__ __launch_bounds__(NQ == 2 ? 512 : 1024) void sp_moments_lr_kernel(Mom
     {
         // the end of the strip closes both accumulators: their sums go to the label they follow, nothing is subtracted
         const bool wl = L.lab < (uint32_t)S, wr = Rr.lab < (uint32_t)S;
-        rec_append(wlog, cnt, ballot64(wl), wl, L, kFlushL, u0, (uint32_t)rs, tab, S, ts, lane);
-        rec_append(wlog, cnt, ballot64(wr), wr, Rr, kFlushR, u0, (uint32_t)rs, tab, S, ts, lane);
+        rec_append(wlog, cnt, ballot64(wl), wl, L, kFlushL, g17, (uint32_t)rs, tab, S, ts, lane, NP);
+        rec_append(wlog, cnt, ballot64(wr), wr, Rr, kFlushR, g17, (uint32_t)rs, tab, S, ts, lane, NP);
     }
-    rec_drain(wlog, cnt, tab, S, ts, lane);
+    rec_drain(wlog, cnt, tab, S, ts, lane, NP);
 
     if (!TABLE_LDS) return;
     __syncthreads();
