@@ -454,8 +454,8 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         MVCHK(c, mvalloc(&shp, N * mv_exchange_shared_bytes())); c->ex_sh = shp;
         MVCHK(c, mvalloc(&c->ex_inE, NV)); MVCHK(c, mvalloc(&c->ex_need, NV)); MVCHK(c, mvalloc(&c->ex_err, NV * 4));
         MVCHK(c, mvalloc(&c->ex_plist, pl)); MVCHK(c, mvalloc(&c->ex_queue, qu));
-        MVCHK(c, mvalloc(&c->ex_counters, 2 * (size_t)G));
-        MVCHK(c, hipMemsetAsync(c->ex_counters, 0, 2 * (size_t)G * sizeof(uint32_t), c->stream));
+        MVCHK(c, mvalloc(&c->ex_counters, kMvExchangeCounters * (size_t)G));
+        MVCHK(c, hipMemsetAsync(c->ex_counters, 0, kMvExchangeCounters * (size_t)G * sizeof(uint32_t), c->stream));
         MVCHK(c, hipMemsetAsync(c->ex_need, 0, NV, c->stream));      // all zero between iterations (MvExchange::need)
         c->ex_groups = G;
     }
@@ -490,7 +490,7 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
             if (x.trace) { x.trace += n0 * a.trace_stride; x.trace_a += n0 * a.trace_stride; }
             ag[gidx] = x;
             bg[gidx] = MvSplitBufs{ static_cast<uint8_t*>(c->ex_sh) + n0 * shb, c->ex_inE + n0 * V, c->ex_need + n0 * V,
-                                    c->ex_err + n0 * V * 4, c->ex_plist + pl, c->ex_queue + qu, c->ex_counters + 2 * gidx };
+                                    c->ex_err + n0 * V * 4, c->ex_plist + pl, c->ex_queue + qu, c->ex_counters + kMvExchangeCounters * gidx };
             pl += mv_split_plist_entries(c->V, (int)(n1 - n0)); qu += mv_split_queue_entries(c->V, (int)(n1 - n0));
             MVCHK(c, hipStreamWaitEvent(c->gstream[gidx], c->gev_start, 0));
         }

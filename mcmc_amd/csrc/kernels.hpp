@@ -161,9 +161,10 @@ hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* o
 hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 // device buffers of the split iteration (capi_multiview.hip allocates them; sizes from the functions below)
+constexpr int kMvExchangeCounters = 2;         // words of MvSplitBufs::counters per group of chains
 struct MvSplitBufs {
     void* sh; uint8_t* inE; uint8_t* need; double* err;     // [C] shared blocks, [C][V], [V][C], [C][4][V]
-    uint16_t* plist; uint4* queue; uint32_t* counters;      // mv_split_plist_entries, mv_split_queue_entries, [2] zeroed once
+    uint16_t* plist; uint4* queue; uint32_t* counters;      // mv_split_plist_entries, mv_split_queue_entries, [kMvExchangeCounters] zeroed once
 };
 size_t mv_split_plist_entries(int V, int n_chains);
 size_t mv_split_queue_entries(int V, int n_chains);

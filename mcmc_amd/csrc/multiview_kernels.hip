@@ -426,7 +426,7 @@ struct MvExchange {
     uint8_t* need;      // [V][C] bit k: the L1 residual of vertex v under plane k of this chain is wanted; zero between
                         // iterations (the first half writes the non-zero codes, mv_err_pairs_kernel clears them again)
     double* err;        // [C][4][V]
-    uint16_t* plist;    // [chain blocks][V][4096] the pairs (chain in block << 2 | plane) that want a vertex's residual
+    uint16_t* plist;    // [queue places][64] the pairs (chain in block << 2 | plane) of an item, beside the item's place in the queue
     uint4* queue;       // [chain blocks * V * 64] items of 64 pairs: .x vertex | chain block << 16, .y item | pairs << 8,
                         // .z first point of the vertex, .w its point count
     unsigned long long* prof;   // option "profile": the L1 kernel's counters [16..23] (mcmc_mv_chains_get_profile), else null
@@ -909,24 +909,58 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
 // movement, the one over g is two cross-row exchanges per group of 16 pairs and item.  Up to four groups of 16
 // pairs share the points of an item.  Measured: 64 cycles per instruction and SIMD (tools/micro/mfma_f64_rate.hip).
 constexpr int kErrChainsPerBlock = 1024;
-constexpr int kErrItemsPerBlock = kErrChainsPerBlock * 4 / kWave;      // at most 64 items per (vertex, chain block)
+constexpr int kErrItemsPerBlock = kErrChainsPerBlock * 4 / 16;         // at most 256 items per (vertex, chain block)
 constexpr int kErrVertsPerGroup = 16;                                  // vertices per workgroup of mv_err_pairs_kernel
 typedef double double4_t __attribute__((ext_vector_type(4)));
+#ifndef MC_MV_ERR_RING
+#define MC_MV_ERR_RING 4
+#endif
+#ifndef MC_MV_ERR_ITEM_COST
+#define MC_MV_ERR_ITEM_COST 128
+#endif
+// An item is one vertex under 16, 32, 48 or 64 pairs, whichever keeps it near kErrItemCost matrix instructions (blocks of
+// 16 points x groups of 16 pairs): a wave holds a fifth of its SIMD's matrix pipe, so the largest item sets how long the
+// kernel lasts (items of 64 pairs whatever the vertex: 248 instructions for the largest vertex at C4 against a mean of 108).
+MC_D uint32_t err_groups_per_item(uint32_t cnt)
+{
+    const uint32_t nblk = (cnt + 15u) >> 4;
+    const uint32_t gq = nblk ? (uint32_t)MC_MV_ERR_ITEM_COST / nblk : 4u;
+    return gq < 1u ? 1u : (gq > 4u ? 4u : gq);
+}
+// blocks of 16 points asked for ahead of the one multiplied: MC_MV_ERR_RING of them for an item of 64 pairs, more for
+// an item of fewer pairs, whose blocks take less time (a block is asked for 16 matrix instructions ahead either way)
+MC_D constexpr int err_ring(int G) { return G == 1 ? 4 * MC_MV_ERR_RING : G == 2 ? 2 * MC_MV_ERR_RING : G == 3 ? (4 * MC_MV_ERR_RING + 2) / 3 : MC_MV_ERR_RING; }
+
+
+#ifdef MC_MV_ERR_CHECK
+// diagnostic build only: out-of-range indices of the L1 kernels are counted and clamped instead of used
+__device__ unsigned long long g_err_chk[16];
+extern "C" int mcmc_mv_debug_check(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_err_chk), sizeof(unsigned long long) * 16);
+}
+#define MC_CHK(slot, cond, val) do { if (!(cond)) { atomicAdd(&g_err_chk[slot], 1ull); g_err_chk[8 + slot] = (unsigned long long)(val); } } while (0)
+#else
+#define MC_CHK(slot, cond, val) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel(MvGraph g, int n_chains, MvExchange x)
 {
-    __shared__ uint32_t n_pairs[kErrVertsPerGroup], q_base;
+    __shared__ uint32_t n_items_of[kErrVertsPerGroup], q_base;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int c0 = (int)blockIdx.y * kErrChainsPerBlock, c1 = min(n_chains, c0 + kErrChainsPerBlock);
     const int slot = (int)blockIdx.x * kErrVertsPerGroup + wave;       // one vertex per wave
-    uint32_t v = 0, np = 0;
+    uint32_t v = 0, np = 0, pb = 0, pcnt = 0, ppi = kWave, at = 0;
+    uint32_t code[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) code[k] = 0u;
     if (slot < g.V) {
+        uint32_t mine = 0;
         v = uni(g.vorder[slot]);                                       // vertices with many points first
-        uint16_t* list = x.plist + ((size_t)blockIdx.y * g.V + v) * (kErrChainsPerBlock * 4);
+        pb = uni(g.pt_ptr[v]); pcnt = uni(g.pt_ptr[v + 1]) - pb;
+        ppi = 16u * err_groups_per_item(pcnt);                         // pairs per item of this vertex
         // lane l looks at chains c0 + 16 l .. + 15: all sixteen codes are fetched before any is used
         uint8_t* row = x.need + (size_t)v * n_chains;
-        uint32_t code[16];
-        uint32_t mine = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int cc = c0 + 16 * lane + k;
@@ -945,85 +979,124 @@ __global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel
             if (lane >= off) incl += t;
         }
         np = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
-        uint32_t at = incl - mine;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            uint32_t cbits = code[k];
-            while (cbits) {
-                const uint32_t pl = (uint32_t)__ffs((int)cbits) - 1u;
-                cbits &= cbits - 1u;
-                list[at++] = (uint16_t)(((uint32_t)(16 * lane + k) << 2) | pl);
-            }
-        }
+        at = incl - mine;
     }
-    if (lane == 0) n_pairs[wave] = np;
+    const uint32_t items = (np + ppi - 1u) / ppi;                      // at most 256
+    if (lane == 0) n_items_of[wave] = items;
     __syncthreads();
     uint32_t my_first = 0, total = 0;
     for (int s = 0; s < kErrVertsPerGroup; ++s) {
         if (s == wave) my_first = total;
-        total += (n_pairs[s] + kWave - 1) / kWave;
+        total += n_items_of[s];
     }
     if (!total) return;
     if (tid == 0) q_base = atomicAdd(x.counters, total);
     __syncthreads();
-    const uint32_t items = (np + kWave - 1) / kWave;                   // at most 64: one per lane
-    if ((uint32_t)lane < items) {
-        const uint32_t b = g.pt_ptr[v];
-        x.queue[q_base + my_first + (uint32_t)lane] = make_uint4(v | ((uint32_t)blockIdx.y << 16), (uint32_t)lane | (np << 8), b, g.pt_ptr[v + 1] - b);
+#ifdef MC_MV_ERR_CHECK
+    const size_t qcap = (size_t)gridDim.y * g.V * kErrItemsPerBlock;
+    MC_CHK(0, (size_t)q_base + my_first + items <= qcap, q_base + my_first + items);
+    if ((size_t)q_base + my_first + items > qcap) return;
+#endif
+    for (uint32_t k = (uint32_t)lane; k < items; k += kWave)
+        x.queue[q_base + my_first + k] = make_uint4(v | ((uint32_t)blockIdx.y << 16), k | (np << 8), pb, pcnt);
+    // the pairs of an item sit where the item's place in the queue says (kWave places each), so that the wave that
+    // takes the item asks for them together with the queue record
+    uint16_t* list = x.plist + (size_t)(q_base + my_first) * kWave;
+    uint32_t ik = at / ppi, ipos = at - ik * ppi;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t cbits = code[k];
+        while (cbits) {
+            const uint32_t pl = (uint32_t)__ffs((int)cbits) - 1u;
+            cbits &= cbits - 1u;
+            MC_CHK(1, ik < items && ipos < ppi, ((unsigned long long)ik << 32) | ipos);
+#ifdef MC_MV_ERR_CHECK
+            if (ik >= items) continue;
+#endif
+            list[ik * kWave + ipos] = (uint16_t)(((uint32_t)(16 * lane + k) << 2) | pl);
+            if (++ipos == ppi) { ipos = 0u; ++ik; }
+        }
     }
 }
 
 template <int G>
-MC_D void err_item(const MvGraph& g, const MvExchange& x, const uint4 rec, int lane, unsigned long long t_item)
+MC_D void err_item(const MvGraph& g, const MvExchange& x, const uint4 rec, uint32_t here, const uint32_t (&l4)[4], uint32_t lw,
+                   int lane, unsigned long long t_item, int x_n_chains)
 {
+    MC_CHK(4, (rec.x & 0xFFFFu) < (uint32_t)g.V && rec.z + rec.w <= g.pt_ptr[g.V], ((unsigned long long)rec.x << 32) | rec.z);
+#ifdef MC_MV_ERR_CHECK
+    if (!((rec.x & 0xFFFFu) < (uint32_t)g.V && rec.z + rec.w <= g.pt_ptr[g.V])) return;
+#endif
+    constexpr int kErrRing = err_ring(G);
     unsigned long long* const prof = t_item ? x.prof : nullptr;      // one item in 16 is timed (the counters are shared)
     const int v = (int)(rec.x & 0xFFFFu), c0 = (int)(rec.x >> 16) * kErrChainsPerBlock;
-    const uint32_t first = (rec.y & 0xFFu) * kWave, np = rec.y >> 8, b = rec.z, cnt = rec.w;
-    const uint16_t* list = x.plist + ((size_t)(rec.x >> 16) * g.V + v) * (kErrChainsPerBlock * 4);
+    const uint32_t b = rec.z, cnt = rec.w;
     const int jl = lane & 15, kl = lane >> 4;
-    // B: component kl (nx ny nz d) of the plane of pair 16 gi + jl; pairs past the list evaluate a zero plane
-    uint32_t pr[G];
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) { const uint32_t idx = first + (uint32_t)(16 * gi + jl); pr[gi] = idx < np ? (uint32_t)list[idx] : 0xFFFFFFFFu; }
-    const uint32_t widx = first + (uint32_t)lane;
-    const uint32_t wpr = (kl < G && widx < np) ? (uint32_t)list[widx] : 0xFFFFFFFFu;      // the pair this lane writes
+    // B: component kl (nx ny nz d) of the plane of pair 16 gi + jl; places past the item's pairs evaluate a zero plane
+    // (every lane loads a plane -- one that exists where it has no pair -- see the note on conditional loads below)
+    const uint32_t wpr = (uint32_t)lane < here ? lw : 0xFFFFFFFFu;      // the pair this lane writes
     double bp[G];
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) bp[gi] = pr[gi] != 0xFFFFFFFFu ? x.sh[c0 + (int)(pr[gi] >> 2)].pl[pr[gi] & 3u][kl] : 0.0;
-    // A: component kl (x y z 1) of point 16 t + jl; four blocks are on their way while one is multiplied
+    for (int gi = 0; gi < G; ++gi) {
+        const bool has = (uint32_t)(16 * gi + jl) < here;
+        uint32_t pr = has ? l4[gi] : 0u;                                 // the block's first chain, plane 0: memory that exists
+        MC_CHK(2, c0 + (int)(pr >> 2) < x_n_chains, ((unsigned long long)pr << 32) | (unsigned)c0);
+#ifdef MC_MV_ERR_CHECK
+        if (c0 + (int)(pr >> 2) >= x_n_chains) pr = 0;
+#endif
+        const double t = x.sh[c0 + (int)(pr >> 2)].pl[pr & 3u][kl];
+        bp[gi] = has ? t : 0.0;
+    }
+    // A: component kl (x y z 1) of point 16 t + jl; kErrRing blocks are on their way while one is multiplied.  Every
+    // lane issues every load (the block index clamped to the vertex's last block; ptsd ends with 16 points of padding):
+    // a load under a condition is merged with its "else" value at once, which makes every wait a wait for all loads.
     const double* pbase = g.ptsd + (size_t)b * 4;             // uniform; the lane's part of the address is a 32-bit offset
     const uint32_t loff = (uint32_t)(jl * 4 + kl);
-    const uint32_t nblk = (cnt + 15u) >> 4, tail = cnt & 15u;
+    const uint32_t nblk = (cnt + 15u) >> 4, nfull = cnt >> 4, tail = cnt & 15u;
+    const uint32_t lastb = (nblk ? nblk : 1u) - 1u;
     const double4_t zero4 = { 0.0, 0.0, 0.0, 0.0 };
     double4_t acc[G];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) acc[gi] = zero4;
-    double ring[4];
+    double ring[kErrRing];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) ring[w] = (uint32_t)w < nblk ? (pbase + (size_t)w * 64)[loff] : 0.0;
+    for (int w = 0; w < kErrRing; ++w) ring[w] = (pbase + (size_t)min((uint32_t)w, lastb) * 64)[loff];
     unsigned long long t_loop = 0ull;
     if (prof) {      // the planes have arrived: everything before the first block
         t_loop = __builtin_readcyclecounter() + (unsigned long long)(d2u(bp[0]) & 1ull) * 0ull;
         if (lane == 0) atomicAdd(prof + 16, t_loop - t_item);
     }
-    for (uint32_t t0 = 0u; t0 < nblk; t0 += 4u) {
+    // complete blocks, kErrRing at a time: nothing but the load, the products and the additions
+    uint32_t t0 = 0u;
+    for (; t0 + (uint32_t)kErrRing <= nfull; t0 += (uint32_t)kErrRing) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t t = t0 + (uint32_t)w;
-            if (t >= nblk) break;
+        for (int w = 0; w < kErrRing; ++w) {
             const double a = ring[w];
-            if (t + 4u < nblk) ring[w] = (pbase + (size_t)(t + 4u) * 64)[loff];
-            const bool cut = tail != 0u && t == nblk - 1u;            // the last block has rows past the vertex's points
+            ring[w] = (pbase + (size_t)min(t0 + (uint32_t)(w + kErrRing), lastb) * 64)[loff];
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) {
-                double4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[gi], zero4, 0, 0, 0);
-                if (cut) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if ((uint32_t)(4 * r + kl) >= tail) d[r] = 0.0;
-                }
+                const double4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[gi], zero4, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[gi][r] += __builtin_fabs(d[r]);
             }
+        }
+    }
+    // what is left: fewer than kErrRing complete blocks and the one with rows past the vertex's points
+#pragma unroll
+    for (int w = 0; w < kErrRing; ++w) {
+        const uint32_t t = t0 + (uint32_t)w;
+        if (t >= nblk) break;
+        const double a = ring[w];
+        const bool cut = t >= nfull;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            double4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[gi], zero4, 0, 0, 0);
+            if (cut) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if ((uint32_t)(4 * r + kl) >= tail) d[r] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[gi][r] += __builtin_fabs(d[r]);
         }
     }
     unsigned long long t_end = 0ull;
@@ -1041,32 +1114,74 @@ MC_D void err_item(const MvGraph& g, const MvExchange& x, const uint4 rec, int l
         if (kl == gi) res = t;
     }
     // lane l writes pair l of the item: the mean, one division per pair
+    MC_CHK(3, wpr == 0xFFFFFFFFu || (c0 + (int)(wpr >> 2) < x_n_chains && v < g.V), ((unsigned long long)wpr << 32) | (unsigned)v);
+#ifdef MC_MV_ERR_CHECK
+    if (wpr != 0xFFFFFFFFu && !(c0 + (int)(wpr >> 2) < x_n_chains && v < g.V)) return;
+#endif
     if (wpr != 0xFFFFFFFFu) x.err[(size_t)(c0 + (int)(wpr >> 2)) * 4 * g.V + (size_t)(wpr & 3u) * g.V + v] = res / (double)cnt;
     if (prof && lane == 0) { atomicAdd(prof + 18, __builtin_readcyclecounter() - t_end); atomicAdd(prof + 19, 1ull); }
 }
 
+#ifdef MC_MV_ERR_TIMELINE
+// diagnostic build only (tools/mv_timeline.py): when and where every item of the last launch ran
+__device__ unsigned long long g_err_tl[16384 * 4];
+extern "C" int mcmc_mv_debug_timeline(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_err_tl), sizeof(unsigned long long) * 16384 * 4);
+}
+#endif
+
 __global__ __launch_bounds__(kWave) void mv_errors_kernel(MvGraph g, int n_chains, MvExchange x)
 {
     const int lane = (int)threadIdx.x;
-    const uint32_t n_items = uni(x.counters[0]);               // cleared by the second half of the iteration
     // Workgroup b runs on XCD b % 8 (round-robin dispatch).  The items of a vertex are neighbours in the queue and read
     // the same points, so runs of 8 items go to one XCD and meet in its L2: wave i of XCD k takes item 8 (8 (i / 8) + k) + i % 8.
     const uint32_t xcd = blockIdx.x & 7u, wi = blockIdx.x >> 3;
     const uint32_t slot = ((wi >> 3) * 8u + xcd) * 8u + (wi & 7u);
-    const unsigned long long t_wave = x.prof ? __builtin_readcyclecounter() : 0ull;
-    for (uint32_t item = slot; item < n_items; item += gridDim.x) {
-        const unsigned long long t_item = (x.prof && (item & 15u) == 0u) ? __builtin_readcyclecounter() : 0ull;
-        uint4 rec = x.queue[item];
-        rec.x = uni(rec.x); rec.y = uni(rec.y); rec.z = uni(rec.z); rec.w = uni(rec.w);
-        const uint32_t here = min((rec.y >> 8) - (rec.y & 0xFFu) * kWave, (uint32_t)kWave);
-        switch ((here + 15u) >> 4) {
-            case 1: err_item<1>(g, x, rec, lane, t_item); break;
-            case 2: err_item<2>(g, x, rec, lane, t_item); break;
-            case 3: err_item<3>(g, x, rec, lane, t_item); break;
-            default: err_item<4>(g, x, rec, lane, t_item); break;
-        }
+    // The record and the pairs of the wave's first item are asked for together with the length of the queue (the
+    // queue and the pair lists are as long as the launch at least, so the place exists whether or not an item is in
+    // it): an item costs its wave two round trips before the first product, this one and the planes + first points.
+    uint4 rec = x.queue[slot];
+    uint32_t l4[4], lw;
+    {
+        const uint16_t* list = x.plist + (size_t)slot * kWave;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) l4[gi] = (uint32_t)list[16 * gi + (lane & 15)];
+        lw = (uint32_t)list[lane];
     }
-    if (x.prof && lane == 0 && slot < n_items && (slot & 15u) == 0u) { atomicAdd(x.prof + 22, 1ull); atomicAdd(x.prof + 23, __builtin_readcyclecounter() - t_wave); }
+    const uint32_t n_items = uni(x.counters[0]);               // cleared by the second half of the iteration
+    if (slot >= n_items) return;
+    const unsigned long long t_wave = x.prof ? __builtin_readcyclecounter() : 0ull;
+    for (uint32_t item = slot;;) {
+        const unsigned long long t_item = (x.prof && (item & 15u) == 0u) ? __builtin_readcyclecounter() : 0ull;
+        rec.x = uni(rec.x); rec.y = uni(rec.y); rec.z = uni(rec.z); rec.w = uni(rec.w);
+        const uint32_t ppi = 16u * err_groups_per_item(rec.w);
+        const uint32_t here = min((rec.y >> 8) - (rec.y & 0xFFu) * ppi, ppi);
+#ifdef MC_MV_ERR_TIMELINE
+        const unsigned long long tl0 = wall_clock64();
+#endif
+        switch ((here + 15u) >> 4) {
+            case 1: err_item<1>(g, x, rec, here, l4, lw, lane, t_item, n_chains); break;
+            case 2: err_item<2>(g, x, rec, here, l4, lw, lane, t_item, n_chains); break;
+            case 3: err_item<3>(g, x, rec, here, l4, lw, lane, t_item, n_chains); break;
+            default: err_item<4>(g, x, rec, here, l4, lw, lane, t_item, n_chains); break;
+        }
+#ifdef MC_MV_ERR_TIMELINE
+        if (lane == 0 && item < 16384u) {
+            g_err_tl[item * 4 + 0] = tl0; g_err_tl[item * 4 + 1] = wall_clock64();
+            g_err_tl[item * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            g_err_tl[item * 4 + 3] = (unsigned long long)((rec.w + 15u) >> 4) * ((here + 15u) >> 4);
+        }
+#endif
+        item += gridDim.x;                                     // queues longer than the launch: rare (16384 waves)
+        if (item >= n_items) break;
+        rec = x.queue[item];
+        const uint16_t* list = x.plist + (size_t)item * kWave;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) l4[gi] = (uint32_t)list[16 * gi + (lane & 15)];
+        lw = (uint32_t)list[lane];
+    }
+    if (x.prof && lane == 0 && (slot & 15u) == 0u) { atomicAdd(x.prof + 22, 1ull); atomicAdd(x.prof + 23, __builtin_readcyclecounter() - t_wave); }
 }
 
 // pMerge (GraphUtils.cpp:11-20): exp(-|w (.) |t2 - t1||^2 T / 2); one thread per pair
@@ -1263,8 +1378,9 @@ hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream
 size_t mv_exchange_shared_bytes() { return sizeof(MvShared); }
 
 // the same `steps` iterations as four kernels per iteration (see mv_chain_run_kernel)
-size_t mv_split_plist_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * (kErrChainsPerBlock * 4); }
-size_t mv_split_queue_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * kErrItemsPerBlock; }
+size_t mv_split_plist_entries(int V, int n_chains) { return mv_split_queue_entries(V, n_chains) * kWave; }      // kWave places per place in the queue
+// kWave places more than items can be: the L1 kernel reads the place of every wave of its launch, a multiple of kWave
+size_t mv_split_queue_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * kErrItemsPerBlock + kWave; }
 
 hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, hipStream_t st, bool split_growth)
 {
@@ -1278,9 +1394,11 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
     const dim3 pgrid((unsigned)((g.V + kErrVertsPerGroup - 1) / kErrVertsPerGroup), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
     if (pgrid.y > 65535u) return hipErrorInvalidValue;      // > 64 M chains per launch: shard the chains
     // error kernel: a fixed number of waves that share the queue; more than the items of a typical iteration would only idle
-    const size_t qmax = mv_split_queue_entries(g.V, a0.n_chains);
+    const size_t qmax = mv_split_queue_entries(g.V, a0.n_chains) - kWave;
     unsigned ewaves = (unsigned)std::min<size_t>((qmax + 63) & ~(size_t)63, 16384);      // a multiple of 64: see the item mapping
-    if (const char* ev = std::getenv("MCMC_MV_EWAVES")) { const long n = std::atol(ev); if (n > 0) ewaves = (unsigned)(((size_t)n + 63) & ~(size_t)63); }   // tuning knob
+    if (const char* ev = std::getenv("MCMC_MV_EWAVES")) { const long n = std::atol(ev); if (n > 0) ewaves = (unsigned)std::min<size_t>(((size_t)n + 63) & ~(size_t)63, (qmax + 63) & ~(size_t)63); }   // tuning knob
+    size_t elds = 0;
+    if (const char* ev = std::getenv("MCMC_MV_EWPS")) { const long n = std::atol(ev); if (n > 0) elds = (size_t)(160 * 1024 / (4 * n)) - 256; }   // tuning knob: waves per SIMD
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
@@ -1291,7 +1409,7 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
         } else
             hipLaunchKernelGGL((mv_chain_run_kernel<1, kMvWavesFirstHalf>), dim3(a.n_chains), dim3(kMvWavesFirstHalf * 64), bytes, st, g, a, x);
         hipLaunchKernelGGL(mv_err_pairs_kernel, pgrid, dim3(kErrVertsPerGroup * kWave), 0, st, g, a.n_chains, x);
-        hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), 0, st, g, a.n_chains, x);
+        hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), elds, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
     }
     return hipGetLastError();
