@@ -35,7 +35,8 @@ struct mcmc_mv {
     void* ex_sh = nullptr; uint8_t *ex_inE = nullptr, *ex_need = nullptr; double* ex_err = nullptr;
     uint16_t* ex_plist = nullptr; uint4* ex_queue = nullptr; uint32_t* ex_counters = nullptr;
     int opt_split = -1;   // -1 automatic (split from 32 chains on), 0 fused, 1 split
-    int opt_split_growth = -1;  // the first half as a growth kernel (eight waves per chain) + a plane-fit kernel: 1 yes, 0 no, -1 when at most 512 chains run
+    int opt_fuse_halves = -1;   // second half of a step + first half of the next as one kernel: 1 yes, 0 no, -1 unless the growth kernel runs apart
+    int opt_split_growth = -1;  // the first half as a growth kernel (eight waves per chain) + a plane-fit kernel: 1 yes, 0 no, -1 when at most 256 chains run (from there on the fused halves win)
                                 // (C4, iteration: 92 -> 83 us for one chain, 146 -> 135 at 256, 159 -> 156 at 512; first half 120 -> 130 at 1024, where the CUs are full either way)
     int opt_groups = 0;   // groups of chains, each running its iterations on a stream of its own: 0 automatic, 1..kMaxGroups
     int ex_groups = 0;    // the group count the exchange buffers were carved for
@@ -397,6 +398,7 @@ int mcmc_mv_set_option(mcmc_mv* c, const char* name, int value)
     if (!c || !name) return MCMC_E_BADARG;
     if (std::string(name) == "split_step") c->opt_split = value;
     else if (std::string(name) == "split_growth") c->opt_split_growth = value;
+    else if (std::string(name) == "fuse_halves") c->opt_fuse_halves = value;
     else if (std::string(name) == "groups" && value >= 0 && value <= mcmc_mv::kMaxGroups) c->opt_groups = value;
     else if (std::string(name) == "profile") c->opt_prof = value;
     else return mfail(c, MCMC_E_BADARG, std::string("mv_set_option: unknown option ") + name);
@@ -467,8 +469,8 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
     if (split && G == 1) {
         const MvSplitBufs bufs{ c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->ex_plist, c->ex_queue, c->ex_counters };
-        const bool sg = !c->opt_prof && (c->opt_split_growth > 0 || (c->opt_split_growth < 0 && c->n <= 512));
-        MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, bufs, c->stream, sg));
+        const bool sg = !c->opt_prof && (c->opt_split_growth > 0 || (c->opt_split_growth < 0 && c->n <= 256));
+        MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, bufs, c->stream, sg, !c->opt_prof && c->opt_fuse_halves != 0));
     } else if (split) {
         if (!c->gev_start) MVCHK(c, hipEventCreateWithFlags(&c->gev_start, hipEventDisableTiming));
         for (int gidx = 0; gidx < G; ++gidx) {
@@ -499,7 +501,8 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
             for (int gidx = 0; gidx < G; ++gidx) {
                 MvChainArgs x = ag[gidx];
                 x.step0 = a.step0 + ts; x.steps = 1; x.trace_first = ts;
-                MVCHK(c, launch_mv_chain_run_split(graph_of(c), x, bg[gidx], c->gstream[gidx], c->opt_split_growth > 0));
+                MVCHK(c, launch_mv_chain_run_split(graph_of(c), x, bg[gidx], c->gstream[gidx], c->opt_split_growth > 0,
+                                                   c->opt_fuse_halves != 0, ts == 0, ts + 1 == steps));
             }
         }
         for (int gidx = 0; gidx < G; ++gidx) {

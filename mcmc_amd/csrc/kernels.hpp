@@ -169,7 +169,10 @@ struct MvSplitBufs {
 size_t mv_split_plist_entries(int V, int n_chains);
 size_t mv_split_queue_entries(int V, int n_chains);
 // split_growth: the first half as two kernels (component growth with more waves per chain, then the plane fits)
-hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a, const MvSplitBufs& bufs, hipStream_t st, bool split_growth = false);
+// fuse_halves: the second half of a step and the first half of the next as one kernel; opens / closes: this call holds the
+// first / last step of the run (a run may come as one call per step, as the groups of chains do)
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a, const MvSplitBufs& bufs, hipStream_t st, bool split_growth = false,
+                                     bool fuse_halves = false, bool opens = true, bool closes = true);
 size_t mv_exchange_shared_bytes();
 size_t mv_chain_lds_bytes(int V);
 hipError_t launch_mv_world_bits(const float* th, const float* w, int dim, int V, int n0, const uint32_t* in_rowp,

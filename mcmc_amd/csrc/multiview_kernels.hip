@@ -467,14 +467,14 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
     unsigned long long* SM = reinterpret_cast<unsigned long long*>(L.sv);   // start's segment as a bitmap, per step
     for (int v = tid; v < V; v += NT) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
     for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
-    if (MODE == 2 || MODE == 3) {
+    if (MODE == 2 || MODE == 3 || MODE == 5) {
         // second half (2) / plane fits after a growth kernel (3): the grown set and the shared block come from the kernel
         // before; the second half also gets the residuals of the error kernel
         for (int v = tid; v < V; v += NT) L.inE[v] = x.inE[(size_t)chain * V + v];
         const uint32_t* src = reinterpret_cast<const uint32_t*>(x.sh + chain);
         uint32_t* dst = reinterpret_cast<uint32_t*>(sh);
         for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 5) {
             L.errv = x.err + (size_t)chain * 4 * V;
             if (chain == 0 && tid == 0) x.counters[0] = 0u;     // the error kernel has drained the queue: empty for the next iteration
         }
@@ -495,8 +495,16 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
 
     for (unsigned long long ts = 0; ts < a.steps; ++ts) {
         const unsigned long long t = a.step0 + ts;
+        // which half this pass is: the kernel's own, or -- MODE 5, two passes -- the second half of step step0, then
+        // the first half of step step0 + 1
+        const int em = MODE == 5 ? (ts == 0 ? 2 : 1) : MODE;
+        if (MODE == 5 && ts == 1) {
+            // the set of the step just finished came with the kernel's prologue: the first half starts from cleared flags
+            for (int v = tid; v < V; v += NT) L.inE[v] = 0;
+            __syncthreads();
+        }
         if (status != 0) {
-            if (MODE != 2 && MODE != 4 && tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
+            if (em != 2 && em != 4 && tid == 0 && a.trace) { a.trace[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0xFF; if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = 0.0; }
             continue;
         }
         MvRng rg = { a.seed, a.chain_offset + (uint32_t)chain, (uint32_t)t, (uint32_t)(t >> 32) };
@@ -507,7 +515,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         // whose trial succeeds whatever the order of the walk: the four waves grow it breadth first, each
         // wave taking frontier vertices in turn, collecting the candidate edges of 64 out-edges at a time and
         // trying them 64 at once (the Philox call is the expensive part; candidates are ~10 % of the edges).
-        if (MODE != 2 && MODE != 3) {
+        if (em != 2 && em != 3) {
             const uint32_t start = mv_draw_at(rg, 0u) % (uint32_t)V;
             const uint16_t cs = L.cur[start];
             if (tid == 0) { L.inE[start] = 1; EB[start >> 6] = 1ull << (start & 63u); L.elist[0] = (uint16_t)start; sh->nE = 1u; }
@@ -634,10 +642,10 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         __syncthreads();
         const uint32_t nE = sh->nE, orig = sh->orig;
         int kind = sh->kind;
-        if (kind == 3 && MODE != 4) {
-            if (MODE == 2) break;                  // frozen and traced by the first half
+        if (kind == 3 && em != 4) {
+            if (em == 2) break;                  // frozen and traced by the first half
             status = -6;
-            if (MODE != 3) {
+            if (em != 3) {
                 for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
                 for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
             }
@@ -645,27 +653,27 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             __syncthreads();
             continue;
         }
-        if (MODE == 2) {
+        if (em == 2) {
             // nothing: the proposal was made by the first half
         } else if (kind == 1 || kind == 3) {
             // addNewSegment (MultiviewSegmentation.cpp:85-110): the vertices really move (the growth kernel leaves that
             // to the kernel that fits the planes, which finds the set in its flags instead of the list)
             const uint32_t tg = sh->target;
-            if (MODE == 3) {
+            if (em == 3) {
                 for (int v = tid; v < V; v += NT)
                     if (L.inE[v]) { pvalid[L.own[v]] = 0; L.own[v] = (uint16_t)tg; }
-            } else if (MODE != 4) {
+            } else if (em != 4) {
                 for (uint32_t i = (uint32_t)tid; i < nE; i += NT) {
                     const uint32_t v = L.elist[i];
                     pvalid[L.own[v]] = 0;
                     L.own[v] = (uint16_t)tg;
                 }
             }
-            if (MODE != 4) {
+            if (em != 4) {
                 if (tid == 0) pvalid[tg] = 0;
                 nseg++; n_split++;
             }
-        } else if (MODE != 3) {
+        } else if (em != 3) {
             // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids, from the rows the growth
             // scan has seen (every grown vertex's row exactly once)
             if (wave == 0) {
@@ -709,7 +717,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         }
         __syncthreads();
         stamp(3);
-        if (MODE == 4) {
+        if (em == 4) {
             // growth kernel done: the set's flags and the shared block go to the kernel that fits the planes
             for (int v = tid; v < V; v += NT) x.inE[(size_t)chain * V + v] = L.inE[v];
             const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
@@ -728,7 +736,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                 if (k == 2) return o == orig && !L.inE[v];
                 return o == target || L.inE[v];
             };
-            if (MODE != 2) {
+            if (em != 2) {
                 double m[10], p5[5];
                 int cached = 0;
                 if (wave == 0) {
@@ -761,7 +769,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             stamp(4);
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
-            if (MODE == 1 || MODE == 3) {
+            if (em == 1 || em == 3) {
                 for (int v = tid; v < V; v += NT) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
@@ -796,7 +804,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                     stamp(7);
                 }
             }
-            if (MODE == 0) {
+            if (em == 0) {
                 // A vertex's 16 partial sums (point index mod 16) live in one row of 16 lanes, so a wave takes four
                 // vertices at a time, one per row; plane k is evaluated for the rows that want it, the tree runs inside
                 // a row (its exchanges are xor 4, 8, 1, 2).
@@ -830,7 +838,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             }
             __syncthreads();
             // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
-            if (MODE != 1 && MODE != 3 && wave < 4 && !sh->have[wave]) {
+            if (em != 1 && em != 3 && wave < 4 && !sh->have[wave]) {
                 // four rows per trip, fetched whether or not they are members (in the split iteration the table is
                 // behind L2 and a fetch per member would be one round trip after the other); only members are
                 // added, in vertex order
@@ -855,7 +863,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             }
             __syncthreads();
         }
-        if (MODE == 1 || MODE == 3) {
+        if (em == 1 || em == 3) {
             // first half done: hand the shared block over (a skipped proposal wants no residuals)
             const uint32_t* src = reinterpret_cast<const uint32_t*>(sh);
             uint32_t* dst = reinterpret_cast<uint32_t*>(x.sh + chain);
@@ -879,7 +887,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             if (a.trace_a) a.trace_a[(size_t)chain * a.trace_stride + a.trace_first + ts] = av;
         }
         // clear the step's flags (the halves of a split step start from cleared LDS instead)
-        if (MODE == 0) {
+        if (em == 0) {
             for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
             for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
             for (int v = tid; v < V; v += NT) L.nb[v] = 0;
@@ -1326,6 +1334,9 @@ static hipError_t mv_set_lds_attr()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<5, kMvWavesFirstHalf>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
@@ -1382,7 +1393,8 @@ size_t mv_split_plist_entries(int V, int n_chains) { return mv_split_queue_entri
 // kWave places more than items can be: the L1 kernel reads the place of every wave of its launch, a multiple of kWave
 size_t mv_split_queue_entries(int V, int n_chains) { return (size_t)((n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock) * V * kErrItemsPerBlock + kWave; }
 
-hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, hipStream_t st, bool split_growth)
+hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, hipStream_t st, bool split_growth,
+                                     bool fuse_halves, bool opens, bool closes)
 {
     if (g.V > kMvMaxV) return hipErrorInvalidValue;
     hipError_t e = mv_set_lds_attr();
@@ -1402,7 +1414,15 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
-        if (split_growth) {
+        // fuse_halves: the second half of the step before and this step's first half are one kernel (MODE 5) -- a chain
+        // goes on to its next proposal as soon as its own residuals are summed, and its state is loaded once; the
+        // first step of a run (opens) has no step before it, the last (closes) gets its second half as a kernel
+        const bool fused = fuse_halves && !split_growth && !(opens && ts == 0);
+        if (fused) {
+            MvChainArgs af = a;
+            af.step0 = a.step0 - 1; af.steps = 2; af.trace_first = a.trace_first - 1;
+            hipLaunchKernelGGL((mv_chain_run_kernel<5, kMvWavesFirstHalf>), dim3(a.n_chains), dim3(kMvWavesFirstHalf * 64), bytes, st, g, af, x);
+        } else if (split_growth) {
             // the growth in a kernel of its own (eight waves per chain within 64 VGPRs), then the plane fits
             hipLaunchKernelGGL((mv_chain_run_kernel<4, kMvGrowthWaves>), dim3(a.n_chains), dim3(kMvGrowthWaves * 64), gbytes, st, g, a, x);
             hipLaunchKernelGGL(mv_chain_run_kernel<3>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
@@ -1410,7 +1430,8 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
             hipLaunchKernelGGL((mv_chain_run_kernel<1, kMvWavesFirstHalf>), dim3(a.n_chains), dim3(kMvWavesFirstHalf * 64), bytes, st, g, a, x);
         hipLaunchKernelGGL(mv_err_pairs_kernel, pgrid, dim3(kErrVertsPerGroup * kWave), 0, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), elds, st, g, a.n_chains, x);
-        hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+        if (!(fuse_halves && !split_growth) || (closes && ts + 1 == a0.steps))
+            hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
     }
     return hipGetLastError();
 }

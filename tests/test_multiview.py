@@ -285,7 +285,7 @@ def test_gpu_matrix_l1_pass_shapes(gpu_mv, n_chains):
 @pytest.mark.parametrize("split_prob,max_new", [(0.3, 16), (1.0, 2)])
 def test_gpu_growth_kernel_apart_changes_nothing(gpu_mv, split_prob, max_new):
     """Option "split_growth": the first half of an iteration as a growth kernel (eight waves per chain) followed by a
-    plane-fit kernel (automatic up to 512 chains).  Same chains as the single kernel and as the oracle, split proposals
+    plane-fit kernel (automatic up to 256 chains).  Same chains as the single kernel and as the oracle, split proposals
     (the vertices move in the second of the two kernels) and the freeze at max_new_segments included."""
     mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
     _load(gpu_mv, mv)
@@ -310,6 +310,43 @@ def test_gpu_growth_kernel_apart_changes_nothing(gpu_mv, split_prob, max_new):
         assert (got[1][2]["status"] == -6).any()                 # some chains ran out of room for new segments
     orc = O.MvChains(mv, 5, seed=6, chain_offset=2, max_new_segments=max_new, split_prob=split_prob)
     of, oa = orc.run(steps)
+    assert np.array_equal(got[1][0][:5], of) and np.array_equal(got[1][1][:5].view(np.uint64), oa.view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split_prob,max_new", [(0.2, 8), (0.9, 2)])
+def test_gpu_fused_halves_change_nothing(gpu_mv, split_prob, max_new):
+    """Option "fuse_halves" (the default of the split iteration): the second half of a step and the first half of the next
+    run as one kernel, so a run of n steps is first half, n - 1 fused kernels, second half.  Same chains as with the
+    halves apart and as the oracle, over runs of one step (no fused kernel at all), two and more, split proposals and
+    the freeze at max_new_segments included."""
+    mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
+    _load(gpu_mv, mv)
+    gpu_mv.vertex_moments()
+    gpu_mv.set_option("split_growth", 0)
+    n, runs = 70, (1, 2, 6)
+    got = {}
+    for fh in (0, 1):
+        gpu_mv.set_option("fuse_halves", fh)
+        gpu_mv.chains_init(n, seed=6, chain_offset=2, max_new_segments=max_new, split_prob=split_prob)
+        fs, as_ = [], []
+        for steps in runs:
+            gpu_mv.chains_set_trace(steps)
+            gpu_mv.chains_run(steps)
+            f, a = gpu_mv.trace()
+            fs.append(f.copy()); as_.append(a.copy())
+        s = gpu_mv.scalars()
+        got[fh] = (np.concatenate(fs, axis=1), np.concatenate(as_, axis=1), {k: v.copy() for k, v in s.items()}, gpu_mv.labels(1).copy())
+    gpu_mv.set_option("fuse_halves", -1)
+    gpu_mv.set_option("split_growth", -1)
+    assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(got[1][1].view(np.uint64), got[0][1].view(np.uint64))
+    for k in got[0][2]:
+        assert np.array_equal(got[1][2][k], got[0][2][k]), k
+    assert np.array_equal(got[1][3], got[0][3])
+    if max_new == 2:
+        assert (got[1][2]["status"] == -6).any()                 # some chains ran out of room for new segments
+    orc = O.MvChains(mv, 5, seed=6, chain_offset=2, max_new_segments=max_new, split_prob=split_prob)
+    of, oa = orc.run(sum(runs))
     assert np.array_equal(got[1][0][:5], of) and np.array_equal(got[1][1][:5].view(np.uint64), oa.view(np.uint64))
 
 
