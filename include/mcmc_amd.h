@@ -368,7 +368,7 @@ int mcmc_mv_chains_init(mcmc_mv *mv, int n_chains, uint32_t seed, uint32_t chain
 /* Tuning: "split_step" 0 one fused kernel per run; 1 or -1 (default) four kernels per iteration with the L1
  * residuals of all chains evaluated on the f64 matrix cores (same results bit for bit; no reference counterpart;
  * faster at every chain count: 111 us against 605 us per iteration for one chain at BASELINE config 4).
- * "groups" 0 (default: two from 2048 chains on) .. 8: the chains run in that many groups, each on a stream of its
+ * "groups" 0 (default: two from 1024 chains on) .. 8: the chains run in that many groups, each on a stream of its
  * own, so that a group waits only for its own slowest chain; same chains whatever the number.  "split_growth" -1
  * (default: up to 256 chains) / 0 / 1: the first half of an iteration as a growth kernel with eight waves per chain
  * followed by a plane-fit kernel (a chain's latency, which is what few chains wait for: 92 -> 83 us per iteration for

@@ -434,13 +434,13 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     // with the chains in G groups, each running its iterations on a stream of its own, a group only waits for ITS
     // slowest chain and the groups' kernels fill each other's tails.  Chains do not interact, so the grouping changes no
     // result.  Each group gets its share of the exchange buffers and sees itself as a whole job (per-chain pointers
-    // advanced to its first chain, chain_offset likewise).  Measured at C4 (tools/mv_groups.py): 4096 chains 6.90 ->
-    // 7.35 M proposals/s with two groups (three the same; from four on the streams outnumber the hardware queues and
-    // it is slower); 1024 chains -- one round of four chains per CU -- gain nothing (5.18 -> 5.16), also not when the
-    // groups are started half an iteration apart.  Automatic: two groups from 2048 chains on.
+    // advanced to its first chain, chain_offset likewise).  Measured at C4 (tools/mv_l1_time.py, MVG=): 4096 chains 7.23 ->
+    // 7.79 M proposals/s with two groups (three the same; from four on the streams outnumber the hardware queues and
+    // it is slower); 1024 chains 5.76 -> 5.95 (with the halves of an iteration apart, round 3's first form, two groups
+    // gained nothing there), 768 and 512 chains nothing.  Automatic: two groups from 1024 chains on.
     int G = 1;
     if (split && !c->opt_prof) {
-        G = c->opt_groups > 0 ? c->opt_groups : (c->n >= 2048 ? 2 : 1);
+        G = c->opt_groups > 0 ? c->opt_groups : (c->n >= 1024 ? 2 : 1);
         G = std::min(G, std::max(1, c->n / 64));
     }
     if (split && c->ex_groups != G) {

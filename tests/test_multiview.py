@@ -353,7 +353,7 @@ def test_gpu_fused_halves_change_nothing(gpu_mv, split_prob, max_new):
 @pytest.mark.gpu
 def test_gpu_chain_groups_change_nothing(gpu_mv):
     """Option "groups": the chains in G groups, each on a stream of its own with its share of the exchange buffers
-    (automatic from 2048 chains on).  Chains do not interact, so every G gives the same chains; 200 chains in three
+    (automatic from 1024 chains on).  Chains do not interact, so every G gives the same chains; 200 chains in three
     unequal groups, against one group and, for the first chains, the oracle."""
     mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
     _load(gpu_mv, mv)
