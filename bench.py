@@ -387,15 +387,25 @@ def multiview_line(host, device, n_chains, steps):
     more = None
     if n_chains == 1024:
         m.set_option("profile", 0)
-        m.chains_init(4096, seed=4, max_new_segments=4 * steps)
-        m.chains_run(steps)
-        m.chains_run(steps)
-        ms4 = m.last_run_ms()
-        more = {"chains": 4096, "proposals_per_s": 4096 * steps / (ms4 * 1e-3), "ms_per_launch": ms4}
+        more = []
+        for nc in (2048, 4096):
+            m.chains_init(nc, seed=4, max_new_segments=4 * steps)
+            m.chains_run(steps)
+            m.chains_run(steps)
+            msn = m.last_run_ms()
+            more.append({"chains": nc, "proposals_per_s": nc * steps / (msn * 1e-3), "ms_per_launch": msn})
     m.close()
     # the first half of the iteration (component growth + plane fits) has no byte stream and no matrix work: what is
     # known about its bound comes from recorded experiments, not from a live counter
+    l1_kernel = {"kind": "recorded, not live: profiles/r03_multiview_kernel_stats.csv, r03_multiview_pmc.txt, r03_mfma_f64_abs_sum.txt, r03_l1_timeline.txt",
+                 "kernel_us_at_1024_chains_one_group": 50.1, "matrix_instructions_per_launch": 874029,
+                 "matrix_pipe_us_at_64_cycles": 21.6, "frac_of_f64_matrix_peak": 0.43,
+                 "ceiling_frac_with_abs_sums_on_the_same_pipe": 0.73, "frac_of_that_ceiling": 0.59,
+                 "note": "the four v_add_f64 |d| per matrix instruction share the f64 pipe with it: a SIMD saturates at 85-88 cycles "
+                         "per product + additions (64 for the product alone); the rest is two round trips per item before its first "
+                         "product and the spread of the SIMDs' totals (DESIGN.md section 5, K4)"}
     first_half = {"kind": "recorded experiments, not live: profiles/r03_multiview_experiments.txt",
+                  "fused_kernel_us_at_1024_chains": 130.8, "what_it_replaces_us": [120.5, 18.6],
                   "kernel_us_at_1024_chains": 119.7, "of_which_growth_us": 75.0, "plane_fits_and_hand_over_us": 40.0,
                   "trial_random_numbers_us": 6.0,
                   "instructions_per_chain_step": {"valu": 24250, "salu": 14630, "lds": 1745, "vmem": 900},
@@ -406,7 +416,7 @@ def multiview_line(host, device, n_chains, steps):
                           "cycles = 80 us) and the launch's slowest chain (2.2x the mean growth); moving instructions between pipes "
                           "(+27 % vector, -9 % scalar) or a third of the row trips left the time unchanged, requesting four rows "
                           "ahead took 11 us off"}
-    return {"more_chains": more, "first_half_model": first_half,
+    return {"more_chains": more, "first_half_model": first_half, "l1_kernel": l1_kernel,
             "workload": "C4: 3 views x 640x480, %d vertices, %d points, %d directed edges, %d chains x %d steps"
                         % (mv.n_vertices, mv.points.shape[0], mv.col.size, n_chains, steps),
             "proposals_per_s": n_chains * steps / (ms * 1e-3), "ms_per_launch": ms,

@@ -213,8 +213,8 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
         }
         et[e].x = erank[e]; et[e].y = x;
     }
-    // the L1 pass's view of the points (mv_errors_kernel): doubles (x, y, z, 1), and the vertices by descending
-    // point count
+    // the L1 pass's view of the points (mv_errors_kernel): doubles (x, y, z, 1), and the vertices in the order their
+    // items are queued
     const size_t P = pt_ptr[V];
     std::vector<double> ptsd((P + 16) * 4, 0.0);
     for (size_t i = 0; i < P; ++i) {
@@ -223,8 +223,12 @@ int mcmc_mv_set_graph(mcmc_mv* c, int V, const uint32_t* pt_ptr, const float* pt
     }
     std::vector<uint32_t> vorder((size_t)V);
     for (int v = 0; v < V; ++v) vorder[(size_t)v] = (uint32_t)v;
+    // by descending cost of a full item (blocks x groups of pairs, mv_err_groups_per_item), then by point count: the L1
+    // kernel's waves take the queue in this order, longest items first
+    auto item_cost = [&](uint32_t v) { const uint32_t n = pt_ptr[v + 1] - pt_ptr[v]; return ((n + 15u) >> 4) * mv_err_groups_per_item(n); };
     std::stable_sort(vorder.begin(), vorder.end(), [&](uint32_t a, uint32_t b2) {
-        return pt_ptr[a + 1] - pt_ptr[a] > pt_ptr[b2 + 1] - pt_ptr[b2]; });
+        const uint32_t ca = item_cost(a), cb = item_cost(b2);
+        return ca != cb ? ca > cb : pt_ptr[a + 1] - pt_ptr[a] > pt_ptr[b2 + 1] - pt_ptr[b2]; });
     MVCHK(c, hipSetDevice(c->device));
     MVCHK(c, hipStreamSynchronize(c->stream));
     free_chains(c); free_graph(c);

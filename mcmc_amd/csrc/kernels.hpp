@@ -161,6 +161,20 @@ hipError_t launch_mv_fit_segment(const MvGraph& g, const uint8_t* mem, double* o
 hipError_t launch_mv_chain_init(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 hipError_t launch_mv_chain_run(const MvGraph& g, const MvChainArgs& a, hipStream_t st);
 // device buffers of the split iteration (capi_multiview.hip allocates them; sizes from the functions below)
+// L1 pass: an item is one vertex under 16, 32, 48 or 64 (chain, plane) pairs, whichever keeps it near kMvErrItemCost matrix
+// instructions (blocks of 16 points x groups of 16 pairs): a wave holds a share of its SIMD's matrix pipe, so the largest
+// item sets how long the kernel lasts (64 pairs whatever the vertex: 248 instructions for the largest vertex of BASELINE
+// config 4 against a mean of 108).  Host and device: the host orders the vertices by the cost of their items.
+#ifndef MC_MV_ERR_ITEM_COST
+#define MC_MV_ERR_ITEM_COST 128
+#endif
+constexpr uint32_t kMvErrItemCost = MC_MV_ERR_ITEM_COST;
+__host__ __device__ inline uint32_t mv_err_groups_per_item(uint32_t cnt)
+{
+    const uint32_t nblk = (cnt + 15u) >> 4;
+    const uint32_t gq = nblk ? kMvErrItemCost / nblk : 4u;
+    return gq < 1u ? 1u : (gq > 4u ? 4u : gq);
+}
 constexpr int kMvExchangeCounters = 2;         // words of MvSplitBufs::counters per group of chains
 struct MvSplitBufs {
     void* sh; uint8_t* inE; uint8_t* need; double* err;     // [C] shared blocks, [C][V], [V][C], [C][4][V]

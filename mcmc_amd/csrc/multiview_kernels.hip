@@ -906,7 +906,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
 //
 // mv_err_pairs_kernel: a wave takes a vertex, packs the (chain, plane) pairs that want the vertex's residual into a
 // list and cuts it into items of up to 64 pairs; the items of a workgroup's 16 vertices go to a queue with one
-// atomic (vertices with many points come first, so the queue is roughly by descending cost).
+// atomic (the vertices come by descending cost of their items, MvGraph::vorder, so the queue is roughly longest first).
 //
 // mv_errors_kernel: a wave takes an item.  The residuals of 16 points under 16 planes are one
 // v_mfma_f64_16x16x4_f64: A = the points (row = point, k = x y z 1), B = the planes (k = nx ny nz d, column = pair),
@@ -923,18 +923,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #ifndef MC_MV_ERR_RING
 #define MC_MV_ERR_RING 4
 #endif
-#ifndef MC_MV_ERR_ITEM_COST
-#define MC_MV_ERR_ITEM_COST 128
-#endif
-// An item is one vertex under 16, 32, 48 or 64 pairs, whichever keeps it near kErrItemCost matrix instructions (blocks of
-// 16 points x groups of 16 pairs): a wave holds a fifth of its SIMD's matrix pipe, so the largest item sets how long the
-// kernel lasts (items of 64 pairs whatever the vertex: 248 instructions for the largest vertex at C4 against a mean of 108).
-MC_D uint32_t err_groups_per_item(uint32_t cnt)
-{
-    const uint32_t nblk = (cnt + 15u) >> 4;
-    const uint32_t gq = nblk ? (uint32_t)MC_MV_ERR_ITEM_COST / nblk : 4u;
-    return gq < 1u ? 1u : (gq > 4u ? 4u : gq);
-}
 // blocks of 16 points asked for ahead of the one multiplied: MC_MV_ERR_RING of them for an item of 64 pairs, more for
 // an item of fewer pairs, whose blocks take less time (a block is asked for 16 matrix instructions ahead either way)
 MC_D constexpr int err_ring(int G) { return G == 1 ? 4 * MC_MV_ERR_RING : G == 2 ? 2 * MC_MV_ERR_RING : G == 3 ? (4 * MC_MV_ERR_RING + 2) / 3 : MC_MV_ERR_RING; }
@@ -964,9 +952,9 @@ __global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel
     for (int k = 0; k < 16; ++k) code[k] = 0u;
     if (slot < g.V) {
         uint32_t mine = 0;
-        v = uni(g.vorder[slot]);                                       // vertices with many points first
+        v = uni(g.vorder[slot]);                                       // vertices with the longest items first
         pb = uni(g.pt_ptr[v]); pcnt = uni(g.pt_ptr[v + 1]) - pb;
-        ppi = 16u * err_groups_per_item(pcnt);                         // pairs per item of this vertex
+        ppi = 16u * mv_err_groups_per_item(pcnt);                         // pairs per item of this vertex
         // lane l looks at chains c0 + 16 l .. + 15: all sixteen codes are fetched before any is used
         uint8_t* row = x.need + (size_t)v * n_chains;
 #pragma unroll
@@ -1163,7 +1151,7 @@ __global__ __launch_bounds__(kWave) void mv_errors_kernel(MvGraph g, int n_chain
     for (uint32_t item = slot;;) {
         const unsigned long long t_item = (x.prof && (item & 15u) == 0u) ? __builtin_readcyclecounter() : 0ull;
         rec.x = uni(rec.x); rec.y = uni(rec.y); rec.z = uni(rec.z); rec.w = uni(rec.w);
-        const uint32_t ppi = 16u * err_groups_per_item(rec.w);
+        const uint32_t ppi = 16u * mv_err_groups_per_item(rec.w);
         const uint32_t here = min((rec.y >> 8) - (rec.y & 0xFFu) * ppi, ppi);
 #ifdef MC_MV_ERR_TIMELINE
         const unsigned long long tl0 = wall_clock64();

@@ -8,6 +8,7 @@ mv = make_multiview(n_views=3, width=640, height=480, n_planes=8, n_superpixels=
 m = host.Multiview()
 m.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, mv.q)
 m.vertex_moments()
+m.set_option("groups", int(os.environ.get("MVG", 1)))      # one group: one L1 launch per iteration
 m.chains_init(int(os.environ.get("CHAINS", 1024)), seed=1)
 m.chains_run(6)
 m.chains_run(1)
