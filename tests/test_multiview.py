@@ -282,6 +282,36 @@ def test_gpu_matrix_l1_pass_shapes(gpu_mv, n_chains):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_sp,n_chains,split_prob,steps", [(40, 700, 0.2, 4), (4, 1100, 1.0, 3)])
+def test_gpu_matrix_l1_pass_large_vertices(gpu_mv, n_sp, n_chains, split_prob, steps):
+    """The L1 pass with vertices of thousands of points: an item is then one vertex under 16, 32 or 48 pairs instead of 64
+    (mv_err_groups_per_item keeps an item near 128 matrix instructions) and the point loads run 16 blocks ahead; in the
+    second case 31 vertices, every proposal a split and 775 pairs per vertex and step on average, so the vertices of
+    16 pairs per item make more items than the 64 lanes of the wave that queues them.  Split iteration = oracle, bit
+    for bit, for every chain."""
+    mv = make_multiview(n_views=2, width=320, height=240, n_planes=3, n_superpixels=n_sp, seed=13)
+    cnt = np.diff(mv.pt_ptr.astype(np.int64))
+    nblk = (cnt + 15) // 16
+    groups = np.clip(128 // np.maximum(nblk, 1), 1, 4)
+    assert (groups == 1).any() and cnt.max() > 2048 and (n_sp != 40 or set(groups.tolist()) >= {1, 2, 3})
+    _load(gpu_mv, mv)
+    gpu_mv.vertex_moments()
+    gpu_mv.set_option("split_step", 1)
+    gpu_mv.chains_init(n_chains, seed=5, max_new_segments=8, split_prob=split_prob)
+    gpu_mv.chains_set_trace(steps)
+    gpu_mv.chains_run(steps)
+    gf, ga = gpu_mv.trace()
+    gs = gpu_mv.scalars()
+    gpu_mv.set_option("split_step", -1)
+    orc = O.MvChains(mv, n_chains, seed=5, max_new_segments=8, split_prob=split_prob)
+    of, oa = orc.run(steps)
+    assert np.array_equal(gf, of) and np.array_equal(ga.view(np.uint64), oa.view(np.uint64))
+    s = orc.scalars()
+    for k in ("n_accept", "n_split", "n_skip", "trace_hash", "n_segments", "status"):
+        assert np.array_equal(gs[k], s[k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("split_prob,max_new", [(0.3, 16), (1.0, 2)])
 def test_gpu_growth_kernel_apart_changes_nothing(gpu_mv, split_prob, max_new):
     """Option "split_growth": the first half of an iteration as a growth kernel (eight waves per chain) followed by a
