@@ -265,6 +265,7 @@ def k1_roofline(host, sc_list, n_frames, reps, device, warm=400):
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg, "min_launch_ms": float(np.min(ms)),
             "median_launch_ms": float(np.median(ms)), "p90_launch_ms": float(np.percentile(ms, 90)),
+            "max_launch_ms": float(np.max(ms)), "launches_over_1p5x_median": int((np.asarray(ms) > 1.5 * np.median(ms)).sum()),
             "launches": reps, "warmup_launches": warm, "traffic": traffic,
             "cold_launch_ms": float(np.mean(cold)), "cold_launch_note": "mean of the first 25 launches after 2 s idle",
             "cold_frac": alg / (float(np.mean(cold)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
