@@ -282,6 +282,34 @@ def test_gpu_matrix_l1_pass_shapes(gpu_mv, n_chains):
 
 
 @pytest.mark.gpu
+def test_gpu_l1_queue_longer_than_the_launch(gpu_mv, monkeypatch):
+    """A wave of the L1 kernel takes further items (item += waves of the launch) when the queue is longer than the
+    launch -- 16384 waves, so only beyond ~2000 chains per group at BASELINE config 4.  Forced here with a launch of 64
+    waves (tuning variable MCMC_MV_EWAVES, read at every run): same chains as with the full launch and as the oracle."""
+    mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
+    _load(gpu_mv, mv)
+    gpu_mv.vertex_moments()
+    n, steps = 300, 5
+    got = []
+    for ew in (None, "64"):
+        if ew is None:
+            monkeypatch.delenv("MCMC_MV_EWAVES", raising=False)
+        else:
+            monkeypatch.setenv("MCMC_MV_EWAVES", ew)
+        gpu_mv.chains_init(n, seed=9, max_new_segments=8, split_prob=0.3)
+        gpu_mv.chains_set_trace(steps)
+        gpu_mv.chains_run(steps)
+        f, a = gpu_mv.trace()
+        got.append((f.copy(), a.copy(), gpu_mv.scalars()["trace_hash"].copy()))
+    monkeypatch.delenv("MCMC_MV_EWAVES", raising=False)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1].view(np.uint64), got[1][1].view(np.uint64))
+    assert np.array_equal(got[0][2], got[1][2])
+    orc = O.MvChains(mv, 6, seed=9, max_new_segments=8, split_prob=0.3)
+    of, oa = orc.run(steps)
+    assert np.array_equal(got[1][0][:6], of) and np.array_equal(got[1][1][:6].view(np.uint64), oa.view(np.uint64))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_sp,n_chains,split_prob,steps", [(40, 700, 0.2, 4), (4, 1100, 1.0, 3)])
 def test_gpu_matrix_l1_pass_large_vertices(gpu_mv, n_sp, n_chains, split_prob, steps):
     """The L1 pass with vertices of thousands of points: an item is then one vertex under 16, 32 or 48 pairs instead of 64
