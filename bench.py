@@ -445,6 +445,12 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # MCMC_BENCH_ONE_GPU=1: a rehearsal of the N-rank job on a box with one GPU -- every rank computes on device 0 and the
+    # collectives go over gloo (RCCL refuses two ranks on one device).  Same sharding, gathers and checks; the rate it
+    # prints is no measurement of anything (the ranks share the GPU) and the line says so.
+    one_gpu = bool(os.environ.get("MCMC_BENCH_ONE_GPU")) and world > 1
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     # MCMC_BENCH_FORCE_DIST=1: rehearse the RCCL path with a single rank (one-GPU boxes)
@@ -453,7 +459,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:      # the one-rank rehearsal, started without a launcher
             os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from mcmc_amd import host
     from mcmc_amd import distributed as D
@@ -531,7 +540,7 @@ def main():
     dt = time.perf_counter() - t0
     k3_ms = ctx.last_kernel_ms(host.K_CHAIN)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -578,6 +587,8 @@ def main():
                    "best_energy": best_e, "best_chain": best_chain, "ranks_gathered": len(per_rank),
                    "marginal_frames_gathered": frames_gathered,
                    "chain_kernel_variant": ctx.last_variant()},
+        **({"rehearsal": "MCMC_BENCH_ONE_GPU: %d ranks on ONE GPU over gloo -- sharding, gathers and checks as on N GPUs; "
+                         "the rate is not a measurement" % world} if one_gpu else {}),
         "statistics": {"visit_capacity": ctx.visit_capacity(), "overflow_sum": int(overflow[0]), "overflow_max": int(overflow[1]),
                        "measured_steps_per_chain": int(total_steps),
                        "note": "Statistics::update visits that found the per-chain visit table full; 0 = every state counted"},
