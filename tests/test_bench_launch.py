@@ -97,14 +97,14 @@ def test_sharded_configs_through_rccl_one_rank(cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["c2", "c3", "c5"])
-def test_two_ranks_on_one_gpu_rehearsal(cfg):
-    """`bench.py --gpus 2` as the driver would start it on a node -- the parent spawns torch.distributed.run, two ranks --
+@pytest.mark.parametrize("cfg,n", [("c2", 2), ("c3", 2), ("c5", 2), ("c3", 4), ("c5", 4)])
+def test_two_ranks_on_one_gpu_rehearsal(cfg, n):
+    """`bench.py --gpus N` (two and four ranks) as the driver would start it on a node -- the parent spawns torch.distributed.run --
     on a box with ONE GPU (MCMC_BENCH_ONE_GPU: both ranks compute on device 0, collectives over gloo; RCCL refuses two
     ranks on a device).  Everything but the transport is what an N-GPU run does: chains / frames placed by global id,
     barrier and max-over-ranks timing, the best labeling and the marginals gathered from both ranks and checked against
     the step counts, rank 0's first chain re-run on the oracle.  The rate it prints measures nothing."""
-    args = ["--gpus", "2", "--config", cfg, "--steps", "1", "--warmup", "1", "--iters-per-step", "60", "--no-roofline",
+    args = ["--gpus", str(n), "--config", cfg, "--steps", "1", "--warmup", "1", "--iters-per-step", "60", "--no-roofline",
             "--cpu-seconds", "1"]
     if cfg == "c2":
         args += ["--chains", "32", "--no-multiview"]
@@ -114,14 +114,14 @@ def test_two_ranks_on_one_gpu_rehearsal(cfg):
         args += ["--total-frames", "8", "--chains-per-frame", "16", "--distinct-scenes", "2"]
     out = _run_bench(args, {"MCMC_BENCH_ONE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     c = out["config"]
-    assert out["n_gpus"] == 2 and c["name"] == cfg and c["ranks_gathered"] == 2 and "rehearsal" in out
+    assert out["n_gpus"] == n and c["name"] == cfg and c["ranks_gathered"] == n and "rehearsal" in out
     assert out["scaling"] == ("weak" if cfg == "c2" else "strong") and out["value"] > 0
-    assert c["chains_total"] == {"c2": 64, "c3": 64, "c5": 128}[cfg]
-    assert c["chains_per_gpu"] == c["chains_total"] // 2
+    assert c["chains_total"] == {"c2": 32 * n, "c3": 64, "c5": 128}[cfg]
+    assert c["chains_per_gpu"] == c["chains_total"] // n
     assert c["marginal_frames_gathered"] == (8 if cfg == "c5" else 1)
     chk = out["cross_rank_check"]                 # the first chain of EACH rank against the oracle, by global chain id
-    assert chk["identical_to_gpu"] is True and len(chk["chains"]) == 2
-    assert sorted(r["chain"] for r in chk["chains"]) == [0, c["chains_per_gpu"]]
+    assert chk["identical_to_gpu"] is True and len(chk["chains"]) == n
+    assert sorted(r["chain"] for r in chk["chains"]) == [k * c["chains_per_gpu"] for k in range(n)]
     assert out["statistics"]["overflow_sum"] == 0
 
 
