@@ -126,8 +126,14 @@ MC_HD double det_sqrt(double x)
     e -= odd;
     const double m = u2d((u & 0x000FFFFFFFFFFFFFull) | ((uint64_t)(1023 + odd) << 52));
     double y = (m + 2.0) / 3.0;
+    // six Newton steps by definition; a step that returns its argument has reached the iteration's fixed point and the
+    // remaining steps would return it again, so they are not run (same bits, four or five divisions instead of six)
 #pragma unroll 1
-    for (int i = 0; i < 6; ++i) y = 0.5 * (y + m / y);
+    for (int i = 0; i < 6; ++i) {
+        const double yn = 0.5 * (y + m / y);
+        if (yn == y) break;
+        y = yn;
+    }
     return y * u2d((uint64_t)(e / 2 + 1023) << 52);
 }
 

@@ -407,11 +407,27 @@ __global__ __launch_bounds__(kMvThreads) void mv_chain_init_kernel(MvGraph g, Mv
     double* planes = a.plane + (size_t)chain * a.seg_cap * 5;
     uint8_t* pvalid = a.segP_valid + (size_t)chain * a.seg_cap;
     for (int s = tid; s < a.seg_cap; s += kMvThreads) pvalid[s] = 0;
-    for (int s = wave; s < nseg; s += kMvWaves) {
-        double m[10], p5[5];
-        pool_moments(g.vm, V, lane, [&](int v) { return L.cur[v] == (uint16_t)s; }, m);
-        plane_from_moments(m, p5);
-        if (lane == 0) for (int k = 0; k < 5; ++k) planes[(size_t)s * 5 + k] = p5[k];
+    // A wave pools the moments of its segments (wave, wave + 4, ...) one after the other -- the pooled sums are defined
+    // by the wave's lane order -- and hands segment i's to lane i; the eigen-solves, a long chain of dependent f64
+    // operations each, then run once for up to 64 segments, one per lane (the same scalar arithmetic per segment).
+    for (int s0 = wave; s0 < nseg; s0 += kMvWaves * kWave) {
+        double mine[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) mine[k] = k == 0 ? 1.0 : 0.0;      // lanes without a segment solve a harmless one
+        for (int i = 0; i < kWave; ++i) {
+            const int s = s0 + i * kMvWaves;
+            if (s >= nseg) break;
+            double m[10];
+            pool_moments(g.vm, V, lane, [&](int v) { return L.cur[v] == (uint16_t)s; }, m);
+            if (lane == i) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) mine[k] = m[k];
+            }
+        }
+        double p5[5];
+        plane_from_moments(mine, p5);
+        const int s = s0 + lane * kMvWaves;
+        if (s < nseg) for (int k = 0; k < 5; ++k) planes[(size_t)s * 5 + k] = p5[k];
     }
     if (tid == 0) {
         a.nseg[chain] = nseg; a.status[chain] = 0;
