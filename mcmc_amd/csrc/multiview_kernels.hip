@@ -758,6 +758,22 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                 if (wave == 0) {
                     for (int k = 0; k < 5; ++k) p5[k] = planes[(size_t)orig * 5 + k];
                     cached = pvalid[orig];
+                    if (MODE == 5) {
+                        // Fused kernel: this wave has no plane to fit, so it does the hand-over while the others solve theirs
+                        // -- which residuals the L1 pass owes this chain (the codes need the sets and whether SA1 / SA2
+                        // have a cached probability, not the planes), the set's flags, and the vertex sets if a split
+                        // moved vertices (they change nowhere else, so the kernel's end has nothing left to write).
+                        const int hh0 = cached, hh1 = kind == 1 ? 0 : (int)pvalid[target];
+                        for (int v = lane; v < V; v += kWave) {
+                            const uint32_t o = L.own[v];
+                            const bool ie = L.inE[v] != 0;
+                            const uint32_t nb4 = (uint32_t)(!hh0 && o == orig) | ((uint32_t)(!hh1 && o == target) << 1) |
+                                                 ((uint32_t)(o == orig && !ie) << 2) | ((uint32_t)(o == target || ie) << 3);
+                            if (nb4) x.need[(size_t)v * a.n_chains + chain] = (uint8_t)nb4;
+                            x.inE[(size_t)chain * V + v] = L.inE[v];
+                            if (kind == 1) gown[v] = (uint16_t)o;
+                        }
+                    }
                 } else if (wave == 1) {
                     if (kind == 1) {
                         pool_moments(g.vm, V, lane, [&](int v) { return L.inE[v] != 0; }, m);
@@ -785,7 +801,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             stamp(4);
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
-            if (em == 1 || em == 3) {
+            if ((em == 1 || em == 3) && MODE != 5) {
                 for (int v = tid; v < V; v += NT) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
@@ -910,7 +926,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         }
         __syncthreads();
     }
-    if (MODE != 2 && MODE != 4) for (int v = tid; v < V; v += NT) gown[v] = L.own[v];
+    if (MODE != 2 && MODE != 4 && MODE != 5) for (int v = tid; v < V; v += NT) gown[v] = L.own[v];   // MODE 5: written when a split moved vertices
     stamp(6);
     if (tid == 0) {
         if (MODE != 2 && MODE != 4) { a.nseg[chain] = nseg; a.status[chain] = status; a.n_split[chain] = n_split; }
