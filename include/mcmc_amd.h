@@ -374,7 +374,7 @@ int mcmc_mv_chains_init(mcmc_mv *mv, int n_chains, uint32_t seed, uint32_t chain
  * followed by a plane-fit kernel (a chain's latency, which is what few chains wait for: 92 -> 83 us per iteration for
  * one chain at config 4); same chains.  "fuse_halves" -1 (default: on unless the growth kernel runs apart) / 0 / 1:
  * the second half of an iteration and the first half of the next as one kernel (a run of n iterations is first half,
- * n - 1 fused kernels, second half: 186 -> 178 us per iteration for 1024 chains at config 4); same chains.
+ * n - 1 fused kernels, second half: 186 -> 174 us per iteration for 1024 chains in one group at config 4); same chains.
  * "profile" 1: cycle counters for mcmc_mv_chains_get_profile (one group, halves apart). */
 int mcmc_mv_set_option(mcmc_mv *mv, const char *name, int value);
 int mcmc_mv_chains_run(mcmc_mv *mv, uint64_t steps);
