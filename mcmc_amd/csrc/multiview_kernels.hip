@@ -480,9 +480,11 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
     const int W64 = g.W64;
     unsigned long long* EB = reinterpret_cast<unsigned long long*>(L.se);
     unsigned long long* NBU = EB + W64;
+    unsigned long long* NBS = reinterpret_cast<unsigned long long*>(L.nb);  // the neighbouring segments of the grown set, a bitmap by initial id (W64 words of the V bytes)
     unsigned long long* SM = reinterpret_cast<unsigned long long*>(L.sv);   // start's segment as a bitmap, per step
-    for (int v = tid; v < V; v += NT) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; L.nb[v] = 0; }
+    for (int v = tid; v < V; v += NT) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; }
     for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
+    for (int w = tid; w < W64; w += NT) NBS[w] = 0ull;
     if (MODE == 2 || MODE == 3 || MODE == 5) {
         // second half (2) / plane fits after a growth kernel (3): the grown set and the shared block come from the kernel
         // before; the second half also gets the residuals of the error kernel
@@ -693,40 +695,40 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             // getNeighborSegments (MultiviewSegmentation.cpp:112-142) on the initial ids, from the rows the growth
             // scan has seen (every grown vertex's row exactly once)
             if (wave == 0) {
-                // the initial ids of the neighbouring vertices (NBU: every neighbour of the set outside start's segment)
+                // the initial ids of the neighbouring vertices (NBU: every neighbour of the set outside start's segment) as a
+                // bitmap of segment ids, word w in lane w: the count is a sum of popcounts and the idx-th neighbour segment
+                // (ascending id) a prefix sum away -- a flag byte per segment cost two scans of V / 64 LDS trips each
                 for (int w0 = 0; w0 < W64; w0 += kWave) {
                     const int w = w0 + lane;
                     unsigned long long u = w < W64 ? NBU[w] : 0ull;
                     while (u) {
                         const int b = __ffsll((unsigned long long)u) - 1;
-                        L.nb[L.cur[w * 64 + b]] = 1;
+                        const uint32_t c = L.cur[w * 64 + b];
+                        atomicOr(&NBS[c >> 6], 1ull << (c & 63u));
                         u &= u - 1ull;
                     }
                 }
                 wave_lds_fence();
-                int nn = 0;
-                for (int b = 0; b < V; b += kWave) {
-                    const int s = b + lane;
-                    nn += __popcll((unsigned long long)__ballot(s < V && L.nb[s] != 0));
+                const unsigned long long nbw = lane < W64 ? NBS[lane] : 0ull;      // W64 <= 64 (kMvMaxV)
+                const int pc = __popcll(nbw);
+                int incl = pc;
+#pragma unroll
+                for (int off = 1; off < kWave; off <<= 1) {
+                    const int t = __shfl_up(incl, off, kWave);
+                    if (lane >= off) incl += t;
                 }
+                const int nn = __shfl(incl, kWave - 1, kWave);
                 uint32_t target = 0;
                 if (nn >= 1) {
                     // round(randbetween(0, n-1)) (PatternedMatcher.cpp:93)
                     const double x = (double)(nn - 1) * mv_unit(mv_draw_at(rg, 2u));
                     const int idx = (int)(x + 0.5);
-                    int seen = 0;
-                    for (int b = 0; b < V; b += kWave) {
-                        const int s = b + lane;
-                        const uint64_t m = __ballot(s < V && L.nb[s] != 0);
-                        const int c = __popcll((unsigned long long)m);
-                        if (idx < seen + c) {
-                            uint64_t mm = m;
-                            for (int r = 0; r < idx - seen; ++r) mm &= mm - 1ull;
-                            target = (uint32_t)(b + __ffsll((unsigned long long)mm) - 1);
-                            break;
-                        }
-                        seen += c;
-                    }
+                    const bool mine = idx >= incl - pc && idx < incl;
+                    unsigned long long mm = nbw;
+                    if (mine) for (int r = 0; r < idx - (incl - pc); ++r) mm &= mm - 1ull;
+                    const uint32_t cand = (uint32_t)(lane * 64 + (mine ? __ffsll((unsigned long long)mm) - 1 : 0));
+                    const uint64_t who = __ballot(mine);
+                    target = (uint32_t)__builtin_amdgcn_readlane((int)cand, who ? __ffsll((unsigned long long)who) - 1 : 0);
                 }
                 if (lane == 0) { sh->nn = nn; sh->target = target; if (nn < 1) sh->kind = 2; }
             }
@@ -922,7 +924,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         if (em == 0) {
             for (uint32_t i = (uint32_t)tid; i < nE; i += NT) L.inE[L.elist[i]] = 0;
             for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
-            for (int v = tid; v < V; v += NT) L.nb[v] = 0;
+            for (int w = tid; w < W64; w += NT) NBS[w] = 0ull;
         }
         __syncthreads();
     }
