@@ -405,14 +405,14 @@ def multiview_line(host, device, n_chains, steps):
     # the first half of the iteration (component growth + plane fits) has no byte stream and no matrix work: what is
     # known about its bound comes from recorded experiments, not from a live counter
     l1_kernel = {"kind": "recorded, not live: profiles/r03_multiview_kernel_stats.csv, r03_multiview_pmc.txt, r03_mfma_f64_abs_sum.txt, r03_l1_timeline.txt",
-                 "kernel_us_at_1024_chains_one_group": 50.1, "matrix_instructions_per_launch": 874029,
+                 "kernel_us_at_1024_chains_one_group": 49.8, "matrix_instructions_per_launch": 874029,
                  "matrix_pipe_us_at_64_cycles": 21.6, "frac_of_f64_matrix_peak": 0.43,
                  "ceiling_frac_with_abs_sums_on_the_same_pipe": 0.73, "frac_of_that_ceiling": 0.59,
                  "note": "the four v_add_f64 |d| per matrix instruction share the f64 pipe with it: a SIMD saturates at 85-88 cycles "
                          "per product + additions (64 for the product alone); the rest is two round trips per item before its first "
                          "product and the spread of the SIMDs' totals (DESIGN.md section 5, K4)"}
     first_half = {"kind": "recorded experiments, not live: profiles/r03_multiview_experiments.txt",
-                  "fused_kernel_us_at_1024_chains": 130.8, "what_it_replaces_us": [120.5, 18.6],
+                  "fused_kernel_us_at_1024_chains": 122.1, "what_it_replaces_us": [116.0, 18.5],
                   "kernel_us_at_1024_chains": 119.7, "of_which_growth_us": 75.0, "plane_fits_and_hand_over_us": 40.0,
                   "trial_random_numbers_us": 6.0,
                   "instructions_per_chain_step": {"valu": 24250, "salu": 14630, "lds": 1745, "vmem": 900},

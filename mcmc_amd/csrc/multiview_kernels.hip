@@ -760,8 +760,9 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                 if (wave == 0) {
                     for (int k = 0; k < 5; ++k) p5[k] = planes[(size_t)orig * 5 + k];
                     cached = pvalid[orig];
-                    if (MODE == 5) {
-                        // Fused kernel: this wave has no plane to fit, so it does the hand-over while the others solve theirs
+                    if (MODE == 5 || MODE == 3) {
+                        // Fused kernel (and the plane-fit kernel that follows a growth kernel): this wave has no plane to fit,
+                        // so it does the hand-over while the others solve theirs
                         // -- which residuals the L1 pass owes this chain (the codes need the sets and whether SA1 / SA2
                         // have a cached probability, not the planes), the set's flags, and the vertex sets if a split
                         // moved vertices (they change nowhere else, so the kernel's end has nothing left to write).
@@ -803,7 +804,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             stamp(4);
             // ---- phase 3: L1 residual pass over the points of the four sets ----
             const int h0 = sh->have[0], h1 = sh->have[1];
-            if ((em == 1 || em == 3) && MODE != 5) {
+            if (em == 1 && MODE != 5) {
                 for (int v = tid; v < V; v += NT) {
                     const uint32_t o = L.own[v];
                     const bool ie = L.inE[v] != 0;
