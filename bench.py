@@ -57,7 +57,7 @@ def parse(argv=None):
     ap.add_argument("--iters-per-step", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--roofline-frames", type=int, default=256)
-    ap.add_argument("--roofline-reps", type=int, default=100)
+    ap.add_argument("--roofline-reps", type=int, default=300)     # the plain mean of all of them: a stray 200 us launch (one in a few hundred) then moves it by 0.5 us, not 1.6
     ap.add_argument("--roofline-warmup", type=int, default=400)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
