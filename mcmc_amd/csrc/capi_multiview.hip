@@ -43,6 +43,12 @@ struct mcmc_mv {
     static constexpr int kMaxGroups = 8;
     hipStream_t gstream[kMaxGroups] = {};
     hipEvent_t gev_start = nullptr, gev_done[kMaxGroups] = {};
+    // growth a step ahead (launch_mv_chain_run_ahead): a stream for the growth kernels, two hand-over slots, events
+    int opt_ahead = -1;   // 1 on, 0 off, -1 automatic: below 3072 chains, unless "groups", "split_growth" or "fuse_halves" are set by hand
+    int opt_ahead_waves = 0;   // waves per chain of the growth kernel that runs ahead: 4, 8, 0 automatic
+    hipStream_t ahead_stream = nullptr;
+    MvAheadBufs ahead{};
+    int ahead_n = 0;      // the chain count the slots were sized for
     int opt_prof = 0;
     unsigned long long* d_prof = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
@@ -82,6 +88,8 @@ void free_chains(mcmc_mv* c)
     mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err); mvfree(c->d_prof);
     mvfree(c->ex_plist); mvfree(c->ex_queue); mvfree(c->ex_counters);
     c->ex_groups = 0;
+    for (int k = 0; k < 2; ++k) { mvfree(c->ahead.inE[k]); uint8_t* p = static_cast<uint8_t*>(c->ahead.sh[k]); mvfree(p); c->ahead.sh[k] = nullptr; }
+    c->ahead_n = 0;
     c->n = 0; c->trace_cap = 0; c->last_steps = 0;
 }
 MvGraph graph_of(const mcmc_mv* c)
@@ -134,6 +142,12 @@ int mcmc_mv_destroy(mcmc_mv* c)
     free_chains(c); free_graph(c); mvfree(c->d_out);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     if (c->gev_start) (void)hipEventDestroy(c->gev_start);
+    if (c->ahead_stream) { (void)hipStreamSynchronize(c->ahead_stream); (void)hipStreamDestroy(c->ahead_stream); }
+    for (int k = 0; k < 2; ++k) {
+        if (c->ahead.ev_g[k]) (void)hipEventDestroy(c->ahead.ev_g[k]);
+        if (c->ahead.ev_c[k]) (void)hipEventDestroy(c->ahead.ev_c[k]);
+    }
+    if (c->ahead.ev_start) (void)hipEventDestroy(c->ahead.ev_start);
     for (int k = 0; k < mcmc_mv::kMaxGroups; ++k) {
         if (c->gev_done[k]) (void)hipEventDestroy(c->gev_done[k]);
         if (c->gstream[k]) { (void)hipStreamSynchronize(c->gstream[k]); (void)hipStreamDestroy(c->gstream[k]); }
@@ -403,6 +417,8 @@ int mcmc_mv_set_option(mcmc_mv* c, const char* name, int value)
     if (std::string(name) == "split_step") c->opt_split = value;
     else if (std::string(name) == "split_growth") c->opt_split_growth = value;
     else if (std::string(name) == "fuse_halves") c->opt_fuse_halves = value;
+    else if (std::string(name) == "growth_ahead") c->opt_ahead = value;
+    else if (std::string(name) == "growth_ahead_waves" && (value == 0 || value == 4 || value == 8)) c->opt_ahead_waves = value;
     else if (std::string(name) == "groups" && value >= 0 && value <= mcmc_mv::kMaxGroups) c->opt_groups = value;
     else if (std::string(name) == "profile") c->opt_prof = value;
     else return mfail(c, MCMC_E_BADARG, std::string("mv_set_option: unknown option ") + name);
@@ -442,10 +458,43 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     // 7.79 M proposals/s with two groups (three the same; from four on the streams outnumber the hardware queues and
     // it is slower); 1024 chains 5.76 -> 5.95 (with the halves of an iteration apart, round 3's first form, two groups
     // gained nothing there), 768 and 512 chains nothing.  Automatic: two groups from 1024 chains on.
+    // Growth a step ahead.  Measured at C4 (tools/mv_l1_time.py, GROWTH_AHEAD=), us per iteration without / with: 1 chain
+    // 67.9 / 50.6, 64: 108.4 / 72.5, 256: 118.4 / 84.8, 512: 136.5 / 101.0, 768: 154.1 / 135.6, 1024: 165.7 / 161.3,
+    // 1536: 224.8 / 204.9, 2048: 267.6 / 260.8, 4096: 496.8 / 509.2 (there the device is full either way and the extra
+    // kernel costs).  Eight growth waves per chain are best where the CUs have room for them or the growth kernel is
+    // many rounds anyway, four in between (512 chains: 101.0 against 109.9, 1024: 161.3 against 166.5).
+    const bool ahead = split && !c->opt_prof &&
+        (c->opt_ahead > 0 || (c->opt_ahead < 0 && c->n < 3072 && c->opt_groups == 0 && c->opt_split_growth < 0 && c->opt_fuse_halves < 0));
+    const int ahead_waves = c->opt_ahead_waves ? c->opt_ahead_waves : ((c->n > 384 && c->n <= 1280) ? 4 : 8);
     int G = 1;
-    if (split && !c->opt_prof) {
+    if (split && !c->opt_prof && !ahead) {
         G = c->opt_groups > 0 ? c->opt_groups : (c->n >= 1024 ? 2 : 1);
         G = std::min(G, std::max(1, c->n / 64));
+    }
+    if (ahead) {
+        if (!c->ahead_stream) {
+            // the growth runs ahead and only has to be done a step later: lowest priority, it takes what the kernels of the
+            // current step leave free (MCMC_MV_AHEAD_PRIO=0: same priority as the main stream; an experiment knob)
+            int lo = 0, hi = 0;
+            MVCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const char* pe = std::getenv("MCMC_MV_AHEAD_PRIO");
+            const int prio = pe ? (std::atoi(pe) < 0 ? hi : (std::atoi(pe) > 0 ? lo : 0)) : lo;
+            MVCHK(c, hipStreamCreateWithPriority(&c->ahead_stream, hipStreamNonBlocking, prio));
+        }
+        for (int k = 0; k < 2; ++k) {
+            if (!c->ahead.ev_g[k]) MVCHK(c, hipEventCreateWithFlags(&c->ahead.ev_g[k], hipEventDisableTiming));
+            if (!c->ahead.ev_c[k]) MVCHK(c, hipEventCreateWithFlags(&c->ahead.ev_c[k], hipEventDisableTiming));
+        }
+        if (!c->ahead.ev_start) MVCHK(c, hipEventCreateWithFlags(&c->ahead.ev_start, hipEventDisableTiming));
+        if (c->ahead_n != c->n) {
+            for (int k = 0; k < 2; ++k) {
+                mvfree(c->ahead.inE[k]); { uint8_t* p8 = static_cast<uint8_t*>(c->ahead.sh[k]); mvfree(p8); c->ahead.sh[k] = nullptr; }
+                uint8_t* shp = nullptr;
+                MVCHK(c, mvalloc(&c->ahead.inE[k], (size_t)c->n * c->V));
+                MVCHK(c, mvalloc(&shp, (size_t)c->n * mv_exchange_shared_bytes())); c->ahead.sh[k] = shp;
+            }
+            c->ahead_n = c->n;
+        }
     }
     if (split && c->ex_groups != G) {
         { uint8_t* p8 = static_cast<uint8_t*>(c->ex_sh); mvfree(p8); c->ex_sh = nullptr; }
@@ -471,7 +520,10 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
         a.prof = c->d_prof;
     }
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (split && G == 1) {
+    if (ahead) {
+        const MvSplitBufs bufs{ c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->ex_plist, c->ex_queue, c->ex_counters };
+        MVCHK(c, launch_mv_chain_run_ahead(graph_of(c), a, bufs, c->ahead, c->stream, c->ahead_stream, ahead_waves));
+    } else if (split && G == 1) {
         const MvSplitBufs bufs{ c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->ex_plist, c->ex_queue, c->ex_counters };
         const bool sg = !c->opt_prof && (c->opt_split_growth > 0 || (c->opt_split_growth < 0 && c->n <= 256));
         MVCHK(c, launch_mv_chain_run_split(graph_of(c), a, bufs, c->stream, sg, !c->opt_prof && c->opt_fuse_halves != 0));

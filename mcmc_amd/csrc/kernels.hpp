@@ -180,6 +180,15 @@ struct MvSplitBufs {
     void* sh; uint8_t* inE; uint8_t* need; double* err;     // [C] shared blocks, [C][V], [V][C], [C][4][V]
     uint16_t* plist; uint4* queue; uint32_t* counters;      // mv_split_plist_entries, mv_split_queue_entries, [kMvExchangeCounters] zeroed once
 };
+// growth a step ahead: two hand-over slots (the set's flags [C][V], the shared blocks [C] x mv_exchange_shared_bytes) and the
+// events that order the growth stream and the main stream
+struct MvAheadBufs {
+    uint8_t* inE[2]; void* sh[2];
+    hipEvent_t ev_g[2], ev_c[2], ev_start;
+};
+// growth_waves: 8 (the growth kernel of the split-growth path) or 4 waves per chain
+hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a, const MvSplitBufs& bufs, const MvAheadBufs& ab,
+                                     hipStream_t st, hipStream_t gst, int growth_waves);
 size_t mv_split_plist_entries(int V, int n_chains);
 size_t mv_split_queue_entries(int V, int n_chains);
 // split_growth: the first half as two kernels (component growth with more waves per chain, then the plane fits)

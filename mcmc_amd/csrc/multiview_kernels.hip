@@ -447,6 +447,11 @@ struct MvExchange {
                         // .z first point of the vertex, .w its point count
     unsigned long long* prof;   // option "profile": the L1 kernel's counters [16..23] (mcmc_mv_chains_get_profile), else null
     uint32_t* counters; // [0] queue length: counted up by mv_err_pairs_kernel, cleared by the second half
+    // growth ahead (MODE 3 / 6): the set's flags [C][V] and the shared blocks [C] that a growth kernel (MODE 4) left for THIS
+    // step -- the growth of a step needs nothing of the steps before it (the trials are tied to the edges and the step,
+    // the segments it walks are the initial ones), so it runs a step ahead on a stream of its own; null: x.inE / x.sh
+    const uint8_t* g_inE;
+    const MvShared* g_sh;
 };
 
 // PatternedMatcher.cpp:58-130.  MODE 0: `steps` whole iterations per launch, one workgroup per chain, the L1
@@ -485,14 +490,16 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
     for (int v = tid; v < V; v += NT) { L.cur[v] = gcur[v]; L.own[v] = gown[v]; L.inE[v] = 0; }
     for (int w = tid; w < 2 * W64; w += NT) EB[w] = 0ull;
     for (int w = tid; w < W64; w += NT) NBS[w] = 0ull;
-    if (MODE == 2 || MODE == 3 || MODE == 5) {
+    if (MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6) {
         // second half (2) / plane fits after a growth kernel (3): the grown set and the shared block come from the kernel
         // before; the second half also gets the residuals of the error kernel
-        for (int v = tid; v < V; v += NT) L.inE[v] = x.inE[(size_t)chain * V + v];
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(x.sh + chain);
+        const uint8_t* in_inE = (MODE == 3 && x.g_inE) ? x.g_inE : x.inE;
+        const MvShared* in_sh = (MODE == 3 && x.g_sh) ? x.g_sh : x.sh;
+        for (int v = tid; v < V; v += NT) L.inE[v] = in_inE[(size_t)chain * V + v];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(in_sh + chain);
         uint32_t* dst = reinterpret_cast<uint32_t*>(sh);
         for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
-        if (MODE == 2 || MODE == 5) {
+        if (MODE == 2 || MODE == 5 || MODE == 6) {
             L.errv = x.err + (size_t)chain * 4 * V;
             if (chain == 0 && tid == 0) x.counters[0] = 0u;     // the error kernel has drained the queue: empty for the next iteration
         }
@@ -515,7 +522,15 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         const unsigned long long t = a.step0 + ts;
         // which half this pass is: the kernel's own, or -- MODE 5, two passes -- the second half of step step0, then
         // the first half of step step0 + 1
-        const int em = MODE == 5 ? (ts == 0 ? 2 : 1) : MODE;
+        // (MODE 6: ... then the plane fits of step step0 + 1 on the set a growth kernel has left)
+        const int em = MODE == 5 ? (ts == 0 ? 2 : 1) : (MODE == 6 ? (ts == 0 ? 2 : 3) : MODE);
+        if (MODE == 6 && ts == 1) {
+            for (int v = tid; v < V; v += NT) L.inE[v] = x.g_inE[(size_t)chain * V + v];
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(x.g_sh + chain);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sh);
+            for (int k = tid; k < (int)(sizeof(MvShared) / 4); k += NT) dst[k] = src[k];
+            __syncthreads();
+        }
         if (MODE == 5 && ts == 1) {
             // the set of the step just finished came with the kernel's prologue: the first half starts from cleared flags
             for (int v = tid; v < V; v += NT) L.inE[v] = 0;
@@ -657,6 +672,15 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                 sh->kind = kind; sh->a = 0.0;
             }
         }
+        if (em == 3 && tid == 0) {
+            // what the growth kernel could not know when it ran ahead: the segment of the start vertex now, and, for a
+            // split proposal, whether there is room and which id the new segment gets
+            sh->orig = L.own[sh->start];
+            if (sh->kind == 1 || sh->kind == 3) {
+                sh->kind = n_split >= (unsigned long long)(a.seg_cap - V) ? 3 : 1;
+                sh->target = (uint32_t)nseg;
+            }
+        }
         __syncthreads();
         const uint32_t nE = sh->nE, orig = sh->orig;
         int kind = sh->kind;
@@ -760,7 +784,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                 if (wave == 0) {
                     for (int k = 0; k < 5; ++k) p5[k] = planes[(size_t)orig * 5 + k];
                     cached = pvalid[orig];
-                    if (MODE == 5 || MODE == 3) {
+                    if (MODE == 5 || MODE == 3 || MODE == 6) {
                         // Fused kernel (and the plane-fit kernel that follows a growth kernel): this wave has no plane to fit,
                         // so it does the hand-over while the others solve theirs
                         // -- which residuals the L1 pass owes this chain (the codes need the sets and whether SA1 / SA2
@@ -929,7 +953,7 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
         }
         __syncthreads();
     }
-    if (MODE != 2 && MODE != 4 && MODE != 5) for (int v = tid; v < V; v += NT) gown[v] = L.own[v];   // MODE 5: written when a split moved vertices
+    if (MODE != 2 && MODE != 4 && MODE != 5 && MODE != 6) for (int v = tid; v < V; v += NT) gown[v] = L.own[v];   // MODE 5: written when a split moved vertices
     stamp(6);
     if (tid == 0) {
         if (MODE != 2 && MODE != 4) { a.nseg[chain] = nseg; a.status[chain] = status; a.n_split[chain] = n_split; }
@@ -1360,6 +1384,12 @@ static hipError_t mv_set_lds_attr()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<5, kMvWavesFirstHalf>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<6>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_chain_run_kernel<3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return e;
@@ -1456,6 +1486,67 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
         if (!(fuse_halves && !split_growth) || (closes && ts + 1 == a0.steps))
             hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
     }
+    return hipGetLastError();
+}
+
+// The same iterations with the growth a step ahead: growth(t + 1) (MODE 4, stream gst, into slot (t + 1) & 1 of the
+// two hand-over buffers) runs while the main stream does [second half of t - 1 + plane fits of t] (MODE 6), the pair
+// lists and the L1 kernel of step t.  ev_g[s]: growth into slot s done; ev_c[s]: the kernel that read slot s done.
+hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, const MvAheadBufs& ab,
+                                     hipStream_t st, hipStream_t gst, int growth_waves)
+{
+    if (g.V > kMvMaxV) return hipErrorInvalidValue;
+    hipError_t e = mv_set_lds_attr();
+    if (e != hipSuccess) return e;
+    const size_t bytes = mv_lds_bytes(g.V, false);
+    const size_t gbytes = mv_lds_bytes(g.V, false, (size_t)(kMvGrowthWaves > kMvWaves ? kMvGrowthWaves : kMvWaves) * 1024);
+    if (bytes > 160 * 1024 - 64 || gbytes > 160 * 1024 - 64) return hipErrorInvalidValue;
+    const dim3 pgrid((unsigned)((g.V + kErrVertsPerGroup - 1) / kErrVertsPerGroup), (unsigned)((a0.n_chains + kErrChainsPerBlock - 1) / kErrChainsPerBlock));
+    if (pgrid.y > 65535u) return hipErrorInvalidValue;
+    const size_t qmax = mv_split_queue_entries(g.V, a0.n_chains) - kWave;
+    const unsigned ewaves = (unsigned)std::min<size_t>((qmax + 63) & ~(size_t)63, 16384);
+    auto growth = [&](unsigned long long ts) {
+        // into slot ts & 1, once the kernel that read that slot two steps ago is done
+        const int slot = (int)(ts & 1ull);
+        if (ts >= 2) hipStreamWaitEvent(gst, ab.ev_c[slot], 0);
+        MvChainArgs a = a0;
+        a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
+        MvExchange gx{};
+        gx.sh = reinterpret_cast<MvShared*>(ab.sh[slot]); gx.inE = ab.inE[slot];
+        if (growth_waves == kMvGrowthWaves)
+            hipLaunchKernelGGL((mv_chain_run_kernel<4, kMvGrowthWaves>), dim3(a.n_chains), dim3(kMvGrowthWaves * 64), gbytes, gst, g, a, gx);
+        else
+            hipLaunchKernelGGL(mv_chain_run_kernel<4>, dim3(a.n_chains), dim3(kMvThreads), bytes, gst, g, a, gx);
+        hipEventRecord(ab.ev_g[slot], gst);
+    };
+    // the state the growth kernels read (labels; status) is ready when the main stream gets here
+    hipEventRecord(ab.ev_start, st);
+    hipStreamWaitEvent(gst, ab.ev_start, 0);
+    if (a0.steps) growth(0);
+    for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
+        const int slot = (int)(ts & 1ull);
+        if (ts + 1 < a0.steps) growth(ts + 1);                 // queued before this step's kernels: it runs beside them
+        MvExchange x{ reinterpret_cast<MvShared*>(bufs.sh), bufs.inE, bufs.need, bufs.err, bufs.plist, bufs.queue, a0.prof, bufs.counters,
+                      ab.inE[slot], reinterpret_cast<const MvShared*>(ab.sh[slot]) };
+        MvChainArgs a = a0;
+        a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
+        hipStreamWaitEvent(st, ab.ev_g[slot], 0);
+        if (ts == 0)
+            hipLaunchKernelGGL(mv_chain_run_kernel<3>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+        else {
+            MvChainArgs af = a;
+            af.step0 = a.step0 - 1; af.steps = 2; af.trace_first = a.trace_first - 1;
+            hipLaunchKernelGGL(mv_chain_run_kernel<6>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, af, x);
+        }
+        hipEventRecord(ab.ev_c[slot], st);
+        hipLaunchKernelGGL(mv_err_pairs_kernel, pgrid, dim3(kErrVertsPerGroup * kWave), 0, st, g, a.n_chains, x);
+        hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), 0, st, g, a.n_chains, x);
+        if (ts + 1 == a0.steps)
+            hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
+    }
+    // nothing of the growth stream may outlive the call's work on the main stream
+    hipEventRecord(ab.ev_start, gst);
+    hipStreamWaitEvent(st, ab.ev_start, 0);
     return hipGetLastError();
 }
 

@@ -409,6 +409,45 @@ def test_gpu_fused_halves_change_nothing(gpu_mv, split_prob, max_new):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split_prob,max_new", [(0.2, 8), (0.9, 2)])
+def test_gpu_growth_a_step_ahead_changes_nothing(gpu_mv, split_prob, max_new):
+    """Option "growth_ahead" (the default below 3072 chains): the growth of step t + 1 (a kernel of its own on a second stream; it needs nothing of the
+    steps before it) runs while the main stream finishes step t - 1, fits the planes of step t and evaluates its
+    residuals.  What the growth kernel cannot know a step ahead -- the start vertex's segment after a split, the id of
+    a new segment, whether there is room for one -- is filled in by the kernel that uses the set.  Same chains as
+    without it and as the oracle over runs of 1, 2, 3 and 6 steps, splits and the freeze at max_new_segments included."""
+    mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
+    _load(gpu_mv, mv)
+    gpu_mv.vertex_moments()
+    n, runs = 70, (1, 2, 3, 6)
+    got = {}
+    for ah, waves in ((0, 0), (1, 4), (2, 8)):                   # off; on with four / eight growth waves per chain
+        gpu_mv.set_option("growth_ahead", min(ah, 1))
+        gpu_mv.set_option("growth_ahead_waves", waves)
+        gpu_mv.chains_init(n, seed=6, chain_offset=2, max_new_segments=max_new, split_prob=split_prob)
+        fs, as_ = [], []
+        for steps in runs:
+            gpu_mv.chains_set_trace(steps)
+            gpu_mv.chains_run(steps)
+            f, a = gpu_mv.trace()
+            fs.append(f.copy()); as_.append(a.copy())
+        s = gpu_mv.scalars()
+        got[ah] = (np.concatenate(fs, axis=1), np.concatenate(as_, axis=1), {k: v.copy() for k, v in s.items()}, gpu_mv.labels(1).copy())
+    gpu_mv.set_option("growth_ahead", -1)
+    gpu_mv.set_option("growth_ahead_waves", 0)
+    for ah in (1, 2):
+        assert np.array_equal(got[ah][0], got[0][0]) and np.array_equal(got[ah][1].view(np.uint64), got[0][1].view(np.uint64))
+        for k in got[0][2]:
+            assert np.array_equal(got[ah][2][k], got[0][2][k]), k
+        assert np.array_equal(got[ah][3], got[0][3])
+    if max_new == 2:
+        assert (got[1][2]["status"] == -6).any()                 # some chains ran out of room for new segments
+    orc = O.MvChains(mv, 5, seed=6, chain_offset=2, max_new_segments=max_new, split_prob=split_prob)
+    of, oa = orc.run(sum(runs))
+    assert np.array_equal(got[1][0][:5], of) and np.array_equal(got[1][1][:5].view(np.uint64), oa.view(np.uint64))
+
+
+@pytest.mark.gpu
 def test_gpu_chain_groups_change_nothing(gpu_mv):
     """Option "groups": the chains in G groups, each on a stream of its own with its share of the exchange buffers
     (automatic from 1024 chains on).  Chains do not interact, so every G gives the same chains; 200 chains in three
