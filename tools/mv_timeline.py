@@ -9,6 +9,7 @@ m = host.Multiview()
 m.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, mv.q)
 m.vertex_moments()
 m.set_option("groups", int(os.environ.get("MVG", 1)))      # one group: one L1 launch per iteration
+m.set_option("growth_ahead", int(os.environ.get("GROWTH_AHEAD", 0)))      # and no growth kernel beside it
 m.chains_init(int(os.environ.get("CHAINS", 1024)), seed=1)
 m.chains_run(6)
 m.chains_run(1)
