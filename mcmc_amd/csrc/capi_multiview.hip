@@ -44,7 +44,7 @@ struct mcmc_mv {
     hipStream_t gstream[kMaxGroups] = {};
     hipEvent_t gev_start = nullptr, gev_done[kMaxGroups] = {};
     // growth a step ahead (launch_mv_chain_run_ahead): a stream for the growth kernels, two hand-over slots, events
-    int opt_ahead = -1;   // 1 on, 0 off, -1 automatic: below 3072 chains, unless "groups", "split_growth" or "fuse_halves" are set by hand
+    int opt_ahead = -1;   // 1 on, 0 off, -1 automatic: up to 1152 chains, unless "groups", "split_growth" or "fuse_halves" are set by hand
     int opt_ahead_waves = 0;   // waves per chain of the growth kernel that runs ahead: 4, 8, 0 automatic
     hipStream_t ahead_stream = nullptr;
     MvAheadBufs ahead{};
@@ -459,28 +459,24 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     // it is slower); 1024 chains 5.76 -> 5.95 (with the halves of an iteration apart, round 3's first form, two groups
     // gained nothing there), 768 and 512 chains nothing.  Automatic: two groups from 1024 chains on.
     // Growth a step ahead.  Measured at C4 (tools/mv_l1_time.py, GROWTH_AHEAD=), us per iteration without / with: 1 chain
-    // 67.9 / 50.6, 64: 108.4 / 72.5, 256: 118.4 / 84.8, 512: 136.5 / 101.0, 768: 154.1 / 135.6, 1024: 165.7 / 161.3,
-    // 1536: 224.8 / 204.9, 2048: 267.6 / 260.8, 4096: 496.8 / 509.2 (there the device is full either way and the extra
-    // kernel costs).  Eight growth waves per chain are best where the CUs have room for them or the growth kernel is
-    // many rounds anyway, four in between (512 chains: 101.0 against 109.9, 1024: 161.3 against 166.5).
+    // 67.9 / 50.6, 64: 108.4 / 72.5, 256: 118.4 / 84.7, 512: 136.5 / 101.0, 768: 154.1 / 135.6, 1024: 165.7 / 160.9,
+    // 1280: 190.8 / 196.0, 1536: 223.5 / 224.0, 1792: 246.5 / 252.9, 2048: 267.6 / 283.1 (from there the device is full
+    // either way and the extra kernel costs).  Eight growth waves per chain are best where the CUs have room for them,
+    // four from 384 chains on (512 chains: 101.0 against 109.9, 1024: 161.3 against 166.5).
     const bool ahead = split && !c->opt_prof &&
-        (c->opt_ahead > 0 || (c->opt_ahead < 0 && c->n < 3072 && c->opt_groups == 0 && c->opt_split_growth < 0 && c->opt_fuse_halves < 0));
-    const int ahead_waves = c->opt_ahead_waves ? c->opt_ahead_waves : ((c->n > 384 && c->n <= 1280) ? 4 : 8);
+        (c->opt_ahead > 0 || (c->opt_ahead < 0 && c->n <= 1152 && c->opt_groups == 0 && c->opt_split_growth < 0 && c->opt_fuse_halves < 0));
+    const int ahead_waves = c->opt_ahead_waves ? c->opt_ahead_waves : (c->n > 384 ? 4 : 8);
     int G = 1;
     if (split && !c->opt_prof && !ahead) {
         G = c->opt_groups > 0 ? c->opt_groups : (c->n >= 1024 ? 2 : 1);
         G = std::min(G, std::max(1, c->n / 64));
     }
     if (ahead) {
-        if (!c->ahead_stream) {
-            // the growth runs ahead and only has to be done a step later: lowest priority, it takes what the kernels of the
-            // current step leave free (MCMC_MV_AHEAD_PRIO=0: same priority as the main stream; an experiment knob)
-            int lo = 0, hi = 0;
-            MVCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-            const char* pe = std::getenv("MCMC_MV_AHEAD_PRIO");
-            const int prio = pe ? (std::atoi(pe) < 0 ? hi : (std::atoi(pe) > 0 ? lo : 0)) : lo;
-            MVCHK(c, hipStreamCreateWithPriority(&c->ahead_stream, hipStreamNonBlocking, prio));
-        }
+        // A stream of ordinary priority: a low-priority stream (hipStreamCreateWithPriority) gained 2 % at 2048 chains, and a
+        // process that holds five or more of them -- one per mcmc_mv handle -- stalls for a minute and a half at its first
+        // run (tools/mv_streams_probe.py: the device has few hardware queues of that class); ordinary streams do not, with
+        // ten handles and two dozen other streams in the process.
+        if (!c->ahead_stream) MVCHK(c, hipStreamCreateWithFlags(&c->ahead_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) {
             if (!c->ahead.ev_g[k]) MVCHK(c, hipEventCreateWithFlags(&c->ahead.ev_g[k], hipEventDisableTiming));
             if (!c->ahead.ev_c[k]) MVCHK(c, hipEventCreateWithFlags(&c->ahead.ev_c[k], hipEventDisableTiming));
