@@ -448,6 +448,43 @@ def test_gpu_growth_a_step_ahead_changes_nothing(gpu_mv, split_prob, max_new):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_gpu_growth_ahead_with_many_handles():
+    """Twelve mcmc_mv handles in one process, each with its main and its growth stream -- six times as many streams as
+    the device has hardware queues: every handle's runs finish promptly and give the chains a single handle gives.
+    (With a low-priority growth stream, five handles in a process stalled for 90 s at the first run:
+    tools/mv_streams_probe.py, which also puts two dozen torch streams beside them.)"""
+    import time
+    from mcmc_amd import host
+    mv = make_multiview(n_views=2, width=48, height=36, n_planes=3, n_superpixels=150, seed=11)
+    handles = []
+    try:
+        for k in range(12):
+            m = host.Multiview(device=0)
+            _load(m, mv)
+            m.vertex_moments()
+            handles.append(m)
+        want = None
+        for rep in range(2):
+            for k, m in enumerate(handles):
+                m.chains_init(300, seed=21, max_new_segments=8, split_prob=0.2)
+                m.chains_set_trace(5)
+                t0 = time.time()
+                m.chains_run(5)
+                assert time.time() - t0 < 20.0
+                f, a = m.trace()
+                if want is None:
+                    want = (f.copy(), a.copy())
+                assert np.array_equal(f, want[0]) and np.array_equal(a.view(np.uint64), want[1].view(np.uint64))
+        orc = O.MvChains(mv, 4, seed=21, max_new_segments=8, split_prob=0.2)
+        of, oa = orc.run(5)
+        assert np.array_equal(want[0][:4], of) and np.array_equal(want[1][:4].view(np.uint64), oa.view(np.uint64))
+    finally:
+        for m in handles:
+            m.close()
+
+
+@pytest.mark.gpu
 def test_gpu_chain_groups_change_nothing(gpu_mv):
     """Option "groups": the chains in G groups, each on a stream of its own with its share of the exchange buffers
     (automatic from 1024 chains on).  Chains do not interact, so every G gives the same chains; 200 chains in three
