@@ -412,6 +412,9 @@ def multiview_line(host, device, n_chains, steps):
                          "per product + additions (64 for the product alone); the rest is two round trips per item before its first "
                          "product and the spread of the SIMDs' totals (DESIGN.md section 5, K4)"}
     first_half = {"kind": "recorded experiments, not live: profiles/r03_multiview_experiments.txt",
+                  "growth_ahead": "up to 1152 chains the growth of step t+1 runs on a second stream beside the plane fits and the "
+                                  "residual pass of step t (it needs nothing of the steps before it); the figures below are of "
+                                  "the kernels run one after the other",
                   "fused_kernel_us_at_1024_chains": 122.1, "what_it_replaces_us": [116.0, 18.5],
                   "kernel_us_at_1024_chains": 119.7, "of_which_growth_us": 75.0, "plane_fits_and_hand_over_us": 40.0,
                   "trial_random_numbers_us": 6.0,
