@@ -16,7 +16,7 @@
 // One workgroup (4 waves) per chain: the data-dependent DFS is serial per chain,
 // the refits and the point pass use all 256 lanes.  All f64 results are produced
 // by IEEE operations in a fixed, documented order
-// (wave-order sums, det_exp / det_sqrt from + - * / only, fixed Jacobi sweeps).
+// (wave-order sums, det_exp / det_sqrt from + - * / only, Jacobi sweeps with one stated stopping rule).
 #include <cstdlib>
 #include "device_math.hpp"
 #include "kernels.hpp"
@@ -41,18 +41,26 @@ constexpr int kMvMaxV = 64 * 64;                // a bitmap row is one 64-bit wo
 struct Sym33 { double a00, a01, a02, a11, a12, a22; };
 struct Mat33 { double m[3][3]; };
 
-// one Jacobi rotation on the (p, q) plane; k is the third index
+// one Jacobi rotation on the (p, q) plane; k is the third index.  Left out when the off-diagonal element is below
+// rounding against the diagonal (apq^2 <= 2^-106 |app aqq|); an angle too small to show in 1 + t^2 takes the short
+// form (oracle/multiview_oracle.c jacobi3: same tests, same order, same bits)
 #define MV_ROT(APP, AQQ, APQ, AKP, AKQ, P, Q)                                          \
     do {                                                                                \
         const double apq = APQ;                                                         \
-        if (apq != 0.0) {                                                               \
+        const double dd = APP * AQQ;                                                    \
+        if (!(apq * apq <= 0x1p-106 * (dd < 0.0 ? -dd : dd))) {                         \
+            rotated = true;                                                             \
             const double theta = (AQQ - APP) / (2.0 * apq);                             \
             const double at = theta < 0.0 ? -theta : theta;                             \
-            double t;                                                                   \
-            if (at > 1e150) t = 1.0 / (2.0 * at);                                       \
-            else t = 1.0 / (at + det_sqrt(at * at + 1.0));                              \
+            double t, c;                                                                \
+            if (at >= 0x1p27) { t = 1.0 / (2.0 * at); c = 1.0; }                        \
+            else {                                                                      \
+                const double h2 = at * at + 1.0;                                        \
+                t = 1.0 / (at + h2 * det_rsqrt(h2));                                    \
+                c = det_rsqrt(t * t + 1.0);                                             \
+            }                                                                           \
             if (theta < 0.0) t = -t;                                                    \
-            const double c = 1.0 / det_sqrt(t * t + 1.0), s = t * c;                    \
+            const double s = t * c;                                                     \
             const double akp = AKP, akq = AKQ;                                          \
             APP = APP - t * apq;                                                        \
             AQQ = AQQ + t * apq;                                                        \
@@ -82,9 +90,11 @@ MC_HD void plane_from_moments(const double* m, double* plane)
         for (int j = 0; j < 3; ++j) V.m[i][j] = i == j ? 1.0 : 0.0;
 #pragma unroll 1
     for (int sweep = 0; sweep < 8; ++sweep) {
+        bool rotated = false;
         MV_ROT(A.a00, A.a11, A.a01, A.a02, A.a12, 0, 1);   // (p,q) = (0,1), k = 2
         MV_ROT(A.a00, A.a22, A.a02, A.a01, A.a12, 0, 2);   // (0,2), k = 1
         MV_ROT(A.a11, A.a22, A.a12, A.a01, A.a02, 1, 2);   // (1,2), k = 0
+        if (!rotated) break;                                // the first sweep that rotates nothing ends them
     }
     int k = 0;
     double best = A.a00;
@@ -1505,10 +1515,12 @@ hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, co
     if (pgrid.y > 65535u) return hipErrorInvalidValue;
     const size_t qmax = mv_split_queue_entries(g.V, a0.n_chains) - kWave;
     const unsigned ewaves = (unsigned)std::min<size_t>((qmax + 63) & ~(size_t)63, 16384);
+    hipError_t first = hipSuccess;                               // the first failure of an event call (the launches report through hipGetLastError)
+    auto keep = [&](hipError_t r) { if (first == hipSuccess && r != hipSuccess) first = r; };
     auto growth = [&](unsigned long long ts) {
         // into slot ts & 1, once the kernel that read that slot two steps ago is done
         const int slot = (int)(ts & 1ull);
-        if (ts >= 2) hipStreamWaitEvent(gst, ab.ev_c[slot], 0);
+        if (ts >= 2) keep(hipStreamWaitEvent(gst, ab.ev_c[slot], 0));
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
         MvExchange gx{};
@@ -1517,11 +1529,11 @@ hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, co
             hipLaunchKernelGGL((mv_chain_run_kernel<4, kMvGrowthWaves>), dim3(a.n_chains), dim3(kMvGrowthWaves * 64), gbytes, gst, g, a, gx);
         else
             hipLaunchKernelGGL(mv_chain_run_kernel<4>, dim3(a.n_chains), dim3(kMvThreads), bytes, gst, g, a, gx);
-        hipEventRecord(ab.ev_g[slot], gst);
+        keep(hipEventRecord(ab.ev_g[slot], gst));
     };
     // the state the growth kernels read (labels; status) is ready when the main stream gets here
-    hipEventRecord(ab.ev_start, st);
-    hipStreamWaitEvent(gst, ab.ev_start, 0);
+    keep(hipEventRecord(ab.ev_start, st));
+    keep(hipStreamWaitEvent(gst, ab.ev_start, 0));
     if (a0.steps) growth(0);
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
         const int slot = (int)(ts & 1ull);
@@ -1530,7 +1542,7 @@ hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, co
                       ab.inE[slot], reinterpret_cast<const MvShared*>(ab.sh[slot]) };
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
-        hipStreamWaitEvent(st, ab.ev_g[slot], 0);
+        keep(hipStreamWaitEvent(st, ab.ev_g[slot], 0));
         if (ts == 0)
             hipLaunchKernelGGL(mv_chain_run_kernel<3>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
         else {
@@ -1538,16 +1550,17 @@ hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, co
             af.step0 = a.step0 - 1; af.steps = 2; af.trace_first = a.trace_first - 1;
             hipLaunchKernelGGL(mv_chain_run_kernel<6>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, af, x);
         }
-        hipEventRecord(ab.ev_c[slot], st);
+        keep(hipEventRecord(ab.ev_c[slot], st));
         hipLaunchKernelGGL(mv_err_pairs_kernel, pgrid, dim3(kErrVertsPerGroup * kWave), 0, st, g, a.n_chains, x);
         hipLaunchKernelGGL(mv_errors_kernel, dim3(ewaves), dim3(kWave), 0, st, g, a.n_chains, x);
         if (ts + 1 == a0.steps)
             hipLaunchKernelGGL(mv_chain_run_kernel<2>, dim3(a.n_chains), dim3(kMvThreads), bytes, st, g, a, x);
     }
     // nothing of the growth stream may outlive the call's work on the main stream
-    hipEventRecord(ab.ev_start, gst);
-    hipStreamWaitEvent(st, ab.ev_start, 0);
-    return hipGetLastError();
+    keep(hipEventRecord(ab.ev_start, gst));
+    keep(hipStreamWaitEvent(st, ab.ev_start, 0));
+    const hipError_t launched = hipGetLastError();
+    return launched != hipSuccess ? launched : first;
 }
 
 }  // namespace mc

@@ -114,23 +114,61 @@ void orc_mv_vertex_moments(const float *pts /* 4 per point */, const uint32_t *p
     }
 }
 
-/* Symmetric 3x3 eigen-decomposition: cyclic Jacobi, 8 fixed sweeps. */
+/* 1 / sqrt(x) for a normal positive x from + - * alone (the rotations below need two square roots each, and a
+ * division costs the device as much as this whole function): x = m 2^e, m in [1, 2); a quadratic seed for
+ * 1 / sqrt(m), three Newton steps r <- r (1.5 - (m / 2) r^2), 1 / sqrt(2) for an odd e, the power of two.
+ * A few units in the last place; every operation is one IEEE rounding, so the device returns the same bits. */
+double orc_det_rsqrt(double x)
+{
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    int e = (int)(u >> 52) - 1023;
+    const int odd = e & 1;
+    e -= odd;
+    uint64_t mu = (u & 0x000FFFFFFFFFFFFFull) | (1023ull << 52);
+    double m;
+    memcpy(&m, &mu, 8);
+    const double hm = 0.5 * m;
+    double r = (0.14496475 * m - 0.72223657) * m + 1.57368075;
+    r = r * (1.5 - hm * (r * r));
+    r = r * (1.5 - hm * (r * r));
+    r = r * (1.5 - hm * (r * r));
+    if (odd) r = r * 0.70710678118654752440;
+    uint64_t su = (uint64_t)(1023 - e / 2) << 52;
+    double sc;
+    memcpy(&sc, &su, 8);
+    return r * sc;
+}
+
+/* Symmetric 3x3 eigen-decomposition: cyclic Jacobi, at most 8 sweeps.
+ * A rotation is left out when its off-diagonal element is below rounding against the diagonal,
+ * apq^2 <= 2^-106 |app aqq| (the relative criterion, which keeps the small eigenvalue of a flat cloud accurate);
+ * the sweeps end with the first one that rotates nothing.  A rotation by an angle too small for t^2 to show in
+ * 1 + t^2 (|theta| >= 2^27) takes t = 1 / (2 theta) and c = 1, which is what the long form rounds to.
+ * (The reference's Eigen::JacobiSVD iterates to convergence as well: MathUtils.cpp:33.) */
 static void jacobi3(double A[3][3], double Vm[3][3])
 {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Vm[i][j] = i == j ? 1.0 : 0.0;
     static const int P[3] = { 0, 0, 1 }, Q[3] = { 1, 2, 2 };
     for (int sweep = 0; sweep < 8; ++sweep) {
+        int rotated = 0;
         for (int r = 0; r < 3; ++r) {
             const int p = P[r], q = Q[r];
             const double apq = A[p][q];
-            if (apq == 0.0) continue;
+            const double dd = A[p][p] * A[q][q];
+            if (apq * apq <= 0x1p-106 * (dd < 0.0 ? -dd : dd)) continue;
+            rotated = 1;
             const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
             const double at = theta < 0.0 ? -theta : theta;
-            double t;
-            if (at > 1e150) t = 1.0 / (2.0 * at);
-            else t = 1.0 / (at + orc_det_sqrt(at * at + 1.0));
+            double t, c;
+            if (at >= 0x1p27) { t = 1.0 / (2.0 * at); c = 1.0; }
+            else {
+                const double h2 = at * at + 1.0;
+                t = 1.0 / (at + h2 * orc_det_rsqrt(h2));
+                c = orc_det_rsqrt(t * t + 1.0);
+            }
             if (theta < 0.0) t = -t;
-            const double c = 1.0 / orc_det_sqrt(t * t + 1.0), s = t * c;
+            const double s = t * c;
             const int k = 3 - p - q;
             const double akp = A[k][p], akq = A[k][q];
             A[p][p] = A[p][p] - t * apq;
@@ -144,6 +182,7 @@ static void jacobi3(double A[3][3], double Vm[3][3])
                 Vm[i][q] = s * vip + c * viq;
             }
         }
+        if (!rotated) break;
     }
 }
 

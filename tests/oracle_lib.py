@@ -67,6 +67,7 @@ def lib():
     L.orc_wave_sum.restype = C.c_double; L.orc_wave_sum.argtypes = [f64p]
     L.orc_wave_prod.restype = C.c_double; L.orc_wave_prod.argtypes = [f64p]
     L.orc_det_sqrt.restype = C.c_double; L.orc_det_sqrt.argtypes = [C.c_double]
+    L.orc_det_rsqrt.restype = C.c_double; L.orc_det_rsqrt.argtypes = [C.c_double]
     L.orc_mv_vertex_moments.argtypes = [f32p, u32p, C.c_int, f64p]
     L.orc_mv_fit_segment.argtypes = [C.c_int, f32p, u32p, f64p, u32p, C.c_int, f64p,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -47,6 +47,18 @@ def test_det_sqrt_against_libm():
     assert math.isnan(O.lib().orc_det_sqrt(-1.0)) and O.lib().orc_det_sqrt(math.inf) == math.inf
 
 
+def test_det_rsqrt_against_libm():
+    # the division-free 1 / sqrt(x) of the Jacobi rotations: arguments there are 1 + t^2 and 1 + theta^2 < 2^55
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([np.exp(rng.uniform(0.0, 80.0, 3000)), rng.uniform(1.0, 2.0, 3000), rng.uniform(2.0, 4.0, 1000),
+                         np.exp(rng.uniform(-700, 700, 1000)), [1.0, 2.0, 4.0, 1.0 + 2.0 ** -52, 2.0 - 2.0 ** -52, 2.0 ** 54 + 4.0]])
+    worst = 0.0
+    for x in xs:
+        got, want = O.lib().orc_det_rsqrt(float(x)), 1.0 / math.sqrt(x)
+        worst = max(worst, abs(got - want) / want)
+    assert worst <= 4.5 * 2.0 ** -53, worst                  # measured: 4.0 (two units in the last place below 1)
+
+
 def test_plane_svd_reference_property():
     # TestMathUtils.cpp:44-60: noisy plane rotated 45 degrees about x, r = 1, step 0.1, sigma 0.01
     rng = np.random.default_rng(3)
