@@ -405,25 +405,25 @@ def multiview_line(host, device, n_chains, steps):
     # the first half of the iteration (component growth + plane fits) has no byte stream and no matrix work: what is
     # known about its bound comes from recorded experiments, not from a live counter
     l1_kernel = {"kind": "recorded, not live: profiles/r03_multiview_kernel_stats.csv, r03_multiview_pmc.txt, r03_mfma_f64_abs_sum.txt, r03_l1_timeline.txt",
-                 "kernel_us_at_1024_chains_one_group": 49.8, "matrix_instructions_per_launch": 874029,
+                 "kernel_us_at_1024_chains_one_group": 50.7, "matrix_instructions_per_launch": 874029,
                  "matrix_pipe_us_at_64_cycles": 21.6, "frac_of_f64_matrix_peak": 0.43,
                  "ceiling_frac_with_abs_sums_on_the_same_pipe": 0.73, "frac_of_that_ceiling": 0.59,
                  "note": "the four v_add_f64 |d| per matrix instruction share the f64 pipe with it: a SIMD saturates at 85-88 cycles "
                          "per product + additions (64 for the product alone); the rest is two round trips per item before its first "
                          "product and the spread of the SIMDs' totals (DESIGN.md section 5, K4)"}
     first_half = {"kind": "recorded experiments, not live: profiles/r03_multiview_experiments.txt",
-                  "growth_ahead": "up to 1152 chains the growth of step t+1 runs on a second stream beside the plane fits and the "
+                  "growth_ahead": "up to 3072 chains the growth of step t+1 runs on a second stream beside the plane fits and the "
                                   "residual pass of step t (it needs nothing of the steps before it); the figures below are of "
                                   "the kernels run one after the other",
-                  "fused_kernel_us_at_1024_chains": 122.1, "what_it_replaces_us": [116.0, 18.5],
-                  "kernel_us_at_1024_chains": 119.7, "of_which_growth_us": 75.0, "plane_fits_and_hand_over_us": 40.0,
+                  "fused_kernel_us_at_1024_chains": 108.9, "what_it_replaces_us": [99.9, 18.6],
+                  "kernel_us_at_1024_chains": 99.9, "of_which_growth_us": 75.0, "plane_fits_and_hand_over_us": 22.0,
                   "trial_random_numbers_us": 6.0,
-                  "instructions_per_chain_step": {"valu": 24250, "salu": 14630, "lds": 1745, "vmem": 900},
-                  "wave_cycles_waiting_share": 0.66, "valu_busy_share_per_simd": 0.53,
+                  "instructions_per_chain_step": {"valu": 20850, "salu": 12090, "lds": 1710, "vmem": 940},
+                  "wave_cycles_waiting_share": 0.59,
                   "one_chain_alone_us": 65.8, "slowest_over_mean_growth": 2.2,
-                  "issue_bound_us": 80.0, "frac_of_issue_bound": 80.0 / 119.7,
-                  "note": "bound: the SIMD's instruction issue over all pipes (42.5 M wave-instructions per launch / 1024 SIMDs x 4.6 "
-                          "cycles = 80 us) and the launch's slowest chain (2.2x the mean growth); moving instructions between pipes "
+                  "issue_bound_us": 68.3, "frac_of_issue_bound": 68.3 / 99.9,
+                  "note": "bound: the SIMD's instruction issue over all pipes (36.5 M wave-instructions per launch / 1024 SIMDs x 4.6 "
+                          "cycles = 68 us) and the launch's slowest chain (2.2x the mean growth); moving instructions between pipes "
                           "(+27 % vector, -9 % scalar) or a third of the row trips left the time unchanged, requesting four rows "
                           "ahead took 11 us off"}
     return {"more_chains": more, "first_half_model": first_half, "l1_kernel": l1_kernel,

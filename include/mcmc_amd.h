@@ -368,13 +368,13 @@ int mcmc_mv_chains_init(mcmc_mv *mv, int n_chains, uint32_t seed, uint32_t chain
 /* Tuning: "split_step" 0 one fused kernel per run; 1 or -1 (default) four kernels per iteration with the L1
  * residuals of all chains evaluated on the f64 matrix cores (same results bit for bit; no reference counterpart;
  * faster at every chain count: 111 us against 605 us per iteration for one chain at BASELINE config 4).
- * "growth_ahead" -1 (default: on up to 1152 chains unless "groups", "split_growth" or "fuse_halves" are set by hand)
+ * "growth_ahead" -1 (default: on up to 3072 chains unless "groups", "split_growth" or "fuse_halves" are set by hand)
  * / 0 / 1: the component growth of iteration t + 1 -- which needs nothing of the iterations before it: its trials belong
  * to the edges and the iteration, the segments it walks are the initial ones -- runs as a kernel of its own on a second
  * stream while the main stream finishes iteration t - 1, fits the planes of iteration t and evaluates its residuals
  * (config 4, per iteration: one chain 68 -> 51 us, 256 chains 118 -> 85, 512 chains 137 -> 101, 1024 chains 166 -> 161;
  * beyond that the device is full either way); same chains.  "growth_ahead_waves" 0 (automatic) / 4 / 8: waves per chain of that kernel.  The options below
- * shape the iteration when the growth does not run ahead (more than 1152 chains, or by hand).
+ * shape the iteration when the growth does not run ahead (more than 3072 chains, or by hand).
  * "groups" 0 (default: two from 1024 chains on) .. 8: the chains run in that many groups, each on a stream of its
  * own, so that a group waits only for its own slowest chain; same chains whatever the number.  "split_growth" -1
  * (default: up to 256 chains) / 0 / 1: the first half of an iteration as a growth kernel with eight waves per chain

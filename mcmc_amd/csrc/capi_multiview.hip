@@ -44,7 +44,7 @@ struct mcmc_mv {
     hipStream_t gstream[kMaxGroups] = {};
     hipEvent_t gev_start = nullptr, gev_done[kMaxGroups] = {};
     // growth a step ahead (launch_mv_chain_run_ahead): a stream for the growth kernels, two hand-over slots, events
-    int opt_ahead = -1;   // 1 on, 0 off, -1 automatic: up to 1152 chains, unless "groups", "split_growth" or "fuse_halves" are set by hand
+    int opt_ahead = -1;   // 1 on, 0 off, -1 automatic: up to 3072 chains, unless "groups", "split_growth" or "fuse_halves" are set by hand
     int opt_ahead_waves = 0;   // waves per chain of the growth kernel that runs ahead: 4, 8, 0 automatic
     hipStream_t ahead_stream = nullptr;
     MvAheadBufs ahead{};
@@ -464,7 +464,7 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     // either way and the extra kernel costs).  Eight growth waves per chain are best where the CUs have room for them,
     // four from 384 chains on (512 chains: 101.0 against 109.9, 1024: 161.3 against 166.5).
     const bool ahead = split && !c->opt_prof &&
-        (c->opt_ahead > 0 || (c->opt_ahead < 0 && c->n <= 1152 && c->opt_groups == 0 && c->opt_split_growth < 0 && c->opt_fuse_halves < 0));
+        (c->opt_ahead > 0 || (c->opt_ahead < 0 && c->n <= 3072 && c->opt_groups == 0 && c->opt_split_growth < 0 && c->opt_fuse_halves < 0));
     const int ahead_waves = c->opt_ahead_waves ? c->opt_ahead_waves : (c->n > 384 ? 4 : 8);
     int G = 1;
     if (split && !c->opt_prof && !ahead) {

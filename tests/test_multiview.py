@@ -423,7 +423,7 @@ def test_gpu_fused_halves_change_nothing(gpu_mv, split_prob, max_new):
 @pytest.mark.gpu
 @pytest.mark.parametrize("split_prob,max_new", [(0.2, 8), (0.9, 2)])
 def test_gpu_growth_a_step_ahead_changes_nothing(gpu_mv, split_prob, max_new):
-    """Option "growth_ahead" (the default up to 1152 chains): the growth of step t + 1 (a kernel of its own on a second stream; it needs nothing of the
+    """Option "growth_ahead" (the default up to 3072 chains): the growth of step t + 1 (a kernel of its own on a second stream; it needs nothing of the
     steps before it) runs while the main stream finishes step t - 1, fits the planes of step t and evaluates its
     residuals.  What the growth kernel cannot know a step ahead -- the start vertex's segment after a split, the id of
     a new segment, whether there is room for one -- is filled in by the kernel that uses the set.  Same chains as

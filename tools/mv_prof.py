@@ -7,7 +7,7 @@ mv = make_multiview(n_views=3, width=640, height=480, n_planes=8, n_superpixels=
 m = host.Multiview()
 m.set_graph(mv.pt_ptr, mv.points, mv.row_ptr, mv.col, mv.q)
 m.vertex_moments()
-if os.environ.get("GROWTH_AHEAD"):             # the growth a step ahead on a stream of its own (the default up to 1152 chains)
+if os.environ.get("GROWTH_AHEAD"):             # the growth a step ahead on a stream of its own (the default up to 3072 chains)
     m.set_option("growth_ahead", int(os.environ["GROWTH_AHEAD"]))
 if os.environ.get("MVG"):                      # groups of chains (the default is two from 1024 chains on)
     m.set_option("groups", int(os.environ["MVG"]))
