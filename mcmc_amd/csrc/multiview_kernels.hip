@@ -43,7 +43,7 @@ struct Mat33 { double m[3][3]; };
 
 // one Jacobi rotation on the (p, q) plane; k is the third index.  Left out when the off-diagonal element is below
 // rounding against the diagonal (apq^2 <= 2^-106 |app aqq|); an angle too small to show in 1 + t^2 takes the short
-// form (oracle/multiview_oracle.c jacobi3: same tests, same order, same bits)
+// form (the CPU restatement used by the tests makes the same tests in the same order: same bits)
 #define MV_ROT(APP, AQQ, APQ, AKP, AKQ, P, Q)                                          \
     do {                                                                                \
         const double apq = APQ;                                                         \
