@@ -49,6 +49,7 @@ struct mcmc_mv {
     hipStream_t ahead_stream = nullptr;
     MvAheadBufs ahead{};
     int ahead_n = 0;      // the chain count the slots were sized for
+    long long ahead_ready_step = -1;   // the step whose growth the last run left in its slot for the next run (-1: none)
     int opt_prof = 0;
     unsigned long long* d_prof = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
@@ -89,7 +90,7 @@ void free_chains(mcmc_mv* c)
     mvfree(c->ex_plist); mvfree(c->ex_queue); mvfree(c->ex_counters);
     c->ex_groups = 0;
     for (int k = 0; k < 2; ++k) { mvfree(c->ahead.inE[k]); uint8_t* p = static_cast<uint8_t*>(c->ahead.sh[k]); mvfree(p); c->ahead.sh[k] = nullptr; }
-    c->ahead_n = 0;
+    c->ahead_n = 0; c->ahead_ready_step = -1;
     c->n = 0; c->trace_cap = 0; c->last_steps = 0;
 }
 MvGraph graph_of(const mcmc_mv* c)
@@ -414,6 +415,7 @@ int mcmc_mv_chains_init(mcmc_mv* c, int n_chains, uint32_t seed, uint32_t offset
 int mcmc_mv_set_option(mcmc_mv* c, const char* name, int value)
 {
     if (!c || !name) return MCMC_E_BADARG;
+    c->ahead_ready_step = -1;             // whatever changes, the next run grows its own first step
     if (std::string(name) == "split_step") c->opt_split = value;
     else if (std::string(name) == "split_growth") c->opt_split_growth = value;
     else if (std::string(name) == "fuse_halves") c->opt_fuse_halves = value;
@@ -499,9 +501,13 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
                 MVCHK(c, mvalloc(&c->ahead.inE[k], (size_t)c->n * c->V));
                 MVCHK(c, mvalloc(&shp, (size_t)c->n * mv_exchange_shared_bytes())); c->ahead.sh[k] = shp;
             }
-            c->ahead_n = c->n;
+            c->ahead_n = c->n; c->ahead_ready_step = -1;
         }
     }
+    // A run leaves the growth of the step after its last one behind (it runs beside the last step's kernels); the next
+    // run of the same chains starts from it.  Any other kind of run, new chains or an option set in between discard it.
+    const bool have_first = ahead && c->ahead_ready_step == (long long)c->step;
+    c->ahead_ready_step = -1;
     if (split && c->ex_groups != G) {
         { uint8_t* p8 = static_cast<uint8_t*>(c->ex_sh); mvfree(p8); c->ex_sh = nullptr; }
         mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err); mvfree(c->ex_plist); mvfree(c->ex_queue); mvfree(c->ex_counters);
@@ -528,7 +534,8 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     MVCHK(c, hipEventRecord(c->ev0, c->stream));
     if (ahead) {
         const MvSplitBufs bufs{ c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->ex_plist, c->ex_queue, c->ex_counters };
-        MVCHK(c, launch_mv_chain_run_ahead(graph_of(c), a, bufs, c->ahead, c->stream, c->ahead_stream, ahead_waves));
+        MVCHK(c, launch_mv_chain_run_ahead(graph_of(c), a, bufs, c->ahead, c->stream, c->ahead_stream, ahead_waves, have_first, true));
+        if (steps) c->ahead_ready_step = (long long)(c->step + steps);
     } else if (split && G == 1) {
         const MvSplitBufs bufs{ c->ex_sh, c->ex_inE, c->ex_need, c->ex_err, c->ex_plist, c->ex_queue, c->ex_counters };
         const bool sg = !c->opt_prof && (c->opt_split_growth > 0 || (c->opt_split_growth < 0 && c->n <= 256));

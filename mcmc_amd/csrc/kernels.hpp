@@ -188,7 +188,7 @@ struct MvAheadBufs {
 };
 // growth_waves: 8 (the growth kernel of the split-growth path) or 4 waves per chain
 hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a, const MvSplitBufs& bufs, const MvAheadBufs& ab,
-                                     hipStream_t st, hipStream_t gst, int growth_waves);
+                                     hipStream_t st, hipStream_t gst, int growth_waves, bool have_first, bool grow_next);
 size_t mv_split_plist_entries(int V, int n_chains);
 size_t mv_split_queue_entries(int V, int n_chains);
 // split_growth: the first half as two kernels (component growth with more waves per chain, then the plane fits)

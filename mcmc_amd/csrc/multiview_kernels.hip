@@ -1502,8 +1502,11 @@ hipError_t launch_mv_chain_run_split(const MvGraph& g, const MvChainArgs& a0, co
 // The same iterations with the growth a step ahead: growth(t + 1) (MODE 4, stream gst, into slot (t + 1) & 1 of the
 // two hand-over buffers) runs while the main stream does [second half of t - 1 + plane fits of t] (MODE 6), the pair
 // lists and the L1 kernel of step t.  ev_g[s]: growth into slot s done; ev_c[s]: the kernel that read slot s done.
+// Slots go by the parity of the absolute step, so that a run can leave the growth of the step after its last one in its
+// slot (grow_next) and the next run of the same chains start from it (have_first) instead of waiting for a growth
+// that nothing runs beside.
 hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, const MvSplitBufs& bufs, const MvAheadBufs& ab,
-                                     hipStream_t st, hipStream_t gst, int growth_waves)
+                                     hipStream_t st, hipStream_t gst, int growth_waves, bool have_first, bool grow_next)
 {
     if (g.V > kMvMaxV) return hipErrorInvalidValue;
     hipError_t e = mv_set_lds_attr();
@@ -1519,7 +1522,7 @@ hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, co
     auto keep = [&](hipError_t r) { if (first == hipSuccess && r != hipSuccess) first = r; };
     auto growth = [&](unsigned long long ts) {
         // into slot ts & 1, once the kernel that read that slot two steps ago is done
-        const int slot = (int)(ts & 1ull);
+        const int slot = (int)((a0.step0 + ts) & 1ull);
         if (ts >= 2) keep(hipStreamWaitEvent(gst, ab.ev_c[slot], 0));
         MvChainArgs a = a0;
         a.step0 = a0.step0 + ts; a.steps = 1; a.trace_first = a0.trace_first + ts;
@@ -1534,10 +1537,10 @@ hipError_t launch_mv_chain_run_ahead(const MvGraph& g, const MvChainArgs& a0, co
     // the state the growth kernels read (labels; status) is ready when the main stream gets here
     keep(hipEventRecord(ab.ev_start, st));
     keep(hipStreamWaitEvent(gst, ab.ev_start, 0));
-    if (a0.steps) growth(0);
+    if (a0.steps && !have_first) growth(0);
     for (unsigned long long ts = 0; ts < a0.steps; ++ts) {
-        const int slot = (int)(ts & 1ull);
-        if (ts + 1 < a0.steps) growth(ts + 1);                 // queued before this step's kernels: it runs beside them
+        const int slot = (int)((a0.step0 + ts) & 1ull);
+        if (ts + 1 < a0.steps || grow_next) growth(ts + 1);    // queued before this step's kernels: it runs beside them
         MvExchange x{ reinterpret_cast<MvShared*>(bufs.sh), bufs.inE, bufs.need, bufs.err, bufs.plist, bufs.queue, a0.prof, bufs.counters,
                       ab.inE[slot], reinterpret_cast<const MvShared*>(ab.sh[slot]) };
         MvChainArgs a = a0;

@@ -445,8 +445,27 @@ def test_gpu_growth_a_step_ahead_changes_nothing(gpu_mv, split_prob, max_new):
             fs.append(f.copy()); as_.append(a.copy())
         s = gpu_mv.scalars()
         got[ah] = (np.concatenate(fs, axis=1), np.concatenate(as_, axis=1), {k: v.copy() for k, v in s.items()}, gpu_mv.labels(1).copy())
-    gpu_mv.set_option("growth_ahead", -1)
+    # a run leaves the growth of the next run's first step behind; another kind of run or an option in between discards it
+    gpu_mv.set_option("growth_ahead", 1)
     gpu_mv.set_option("growth_ahead_waves", 0)
+    gpu_mv.chains_init(n, seed=6, chain_offset=2, max_new_segments=max_new, split_prob=split_prob)
+    gpu_mv.chains_run(2)
+    gpu_mv.chains_run(0)
+    gpu_mv.chains_run(1)                                         # starts from the growth the run before left
+    gpu_mv.set_option("growth_ahead", 0)
+    gpu_mv.chains_run(2)
+    gpu_mv.set_option("growth_ahead", 1)
+    gpu_mv.chains_run(3)
+    gpu_mv.chains_set_trace(4)
+    gpu_mv.chains_run(4)                                         # the last four of the twelve steps, traced
+    f, a = gpu_mv.trace()
+    assert np.array_equal(f, got[0][0][:, 8:]) and np.array_equal(a.view(np.uint64), got[0][1][:, 8:].view(np.uint64))
+    s = gpu_mv.scalars()
+    for k in got[0][2]:
+        if k != "trace_hash":
+            assert np.array_equal(s[k], got[0][2][k]), k
+    assert np.array_equal(gpu_mv.labels(1), got[0][3])
+    gpu_mv.set_option("growth_ahead", -1)
     for ah in (1, 2):
         assert np.array_equal(got[ah][0], got[0][0]) and np.array_equal(got[ah][1].view(np.uint64), got[0][1].view(np.uint64))
         for k in got[0][2]:
