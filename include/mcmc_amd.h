@@ -372,8 +372,9 @@ int mcmc_mv_chains_init(mcmc_mv *mv, int n_chains, uint32_t seed, uint32_t chain
  * / 0 / 1: the component growth of iteration t + 1 -- which needs nothing of the iterations before it: its trials belong
  * to the edges and the iteration, the segments it walks are the initial ones -- runs as a kernel of its own on a second
  * stream while the main stream finishes iteration t - 1, fits the planes of iteration t and evaluates its residuals
- * (config 4, per iteration: one chain 68 -> 51 us, 256 chains 118 -> 85, 512 chains 137 -> 101, 1024 chains 166 -> 161;
- * beyond that the device is full either way); same chains.  "growth_ahead_waves" 0 (automatic) / 4 / 8: waves per chain of that kernel.  The options below
+ * (config 4, per iteration: one chain 68 -> 42 us, 256 chains 118 -> 71, 1024 chains 152 -> 141, 2048 chains 242 -> 238);
+ * same chains.  A run also grows the step after its last one, and the next mcmc_mv_chains_run on the same chains starts
+ * from it (mcmc_mv_chains_init, mcmc_mv_set_graph, mcmc_mv_set_option or a run of another kind in between discard it).  "growth_ahead_waves" 0 (automatic) / 4 / 8: waves per chain of that kernel.  The options below
  * shape the iteration when the growth does not run ahead (more than 3072 chains, or by hand).
  * "groups" 0 (default: two from 1024 chains on) .. 8: the chains run in that many groups, each on a stream of its
  * own, so that a group waits only for its own slowest chain; same chains whatever the number.  "split_growth" -1
