@@ -145,7 +145,7 @@ double orc_det_rsqrt(double x)
  * apq^2 <= 2^-106 |app aqq| (the relative criterion, which keeps the small eigenvalue of a flat cloud accurate);
  * the sweeps end with the first one that rotates nothing.  A rotation by an angle too small for t^2 to show in
  * 1 + t^2 (|theta| >= 2^27) takes t = 1 / (2 theta) and c = 1, which is what the long form rounds to.
- * (The reference's Eigen::JacobiSVD iterates to convergence as well: MathUtils.cpp:33.) */
+ * (The reference's Eigen::JacobiSVD iterates to convergence as well: MathUtils.cpp:35.) */
 static void jacobi3(double A[3][3], double Vm[3][3])
 {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Vm[i][j] = i == j ? 1.0 : 0.0;

@@ -105,6 +105,55 @@ def test_segment_fit_against_numpy_svd(mv_small):
         assert abs(prob - p_np) <= REL * p_np + 1e-300
 
 
+def _hard_clouds():
+    rng = np.random.default_rng(8)
+    g = np.arange(-1.0, 1.01, 0.25)
+    x, y = [a.ravel() for a in np.meshgrid(g, g, indexing="ij")]
+    z0 = np.zeros_like(x)
+    Rz = lambda t: np.array([[math.cos(t), -math.sin(t), 0], [math.sin(t), math.cos(t), 0], [0, 0, 1.0]])
+    Rx = lambda t: np.array([[1.0, 0, 0], [0, math.cos(t), -math.sin(t)], [0, math.sin(t), math.cos(t)]])
+    R = Rz(0.7) @ Rx(1.1)
+    clouds = {
+        "exact plane z = 0": np.stack([x, y, z0], 1),
+        "exact plane, tilted": np.stack([x, y, z0], 1) @ R.T,
+        "thin slab 1e-6": (np.stack([x, y, 1e-6 * rng.normal(size=x.size)], 1)) @ R.T,
+        "spread 1e4 : 1 : 1e-3": (np.stack([1e4 * x, y, 1e-3 * rng.normal(size=x.size)], 1)) @ R.T,
+        "far from the origin": np.stack([x, y, 0.01 * rng.normal(size=x.size)], 1) @ R.T + np.array([300.0, -200.0, 500.0]),
+        "small scale 1e-3": 1e-3 * (np.stack([x, y, 0.01 * rng.normal(size=x.size)], 1) @ R.T),
+        "nearly isotropic": rng.normal(size=(200, 3)) * np.array([1.0, 1.0 + 1e-9, 0.5]),
+    }
+    degenerate = {"a line": np.stack([g, 2 * g, -g], 1), "one point nine times": np.tile([[1.0, 2.0, 3.0]], (9, 1))}
+    return clouds, degenerate
+
+
+def test_plane_fit_hard_clouds():
+    """The Jacobi sweeps of the plane fit stop by a relative criterion: clouds whose scatter has zero, tiny, equal or
+    widely spread eigenvalues against numpy's SVD (normal up to sign where the smallest eigenvalue is simple)."""
+    clouds, degenerate = _hard_clouds()
+    for name, P in clouds.items():
+        pts = np.concatenate([P.astype(np.float32), np.ones((P.shape[0], 1), np.float32)], axis=1)
+        pt_ptr = np.array([0, pts.shape[0]], np.uint32)
+        vm = O.mv_vertex_moments(pts, pt_ptr)
+        pl, prob, err = O.mv_fit_segment(pts, pt_ptr, vm, [0])
+        assert np.isfinite(pl).all() and abs(np.linalg.norm(pl[:3]) - 1.0) < 1e-12, (name, pl)
+        n, d, det, e_np, p_np = _numpy_fit([pts])
+        sgn = np.sign(n @ pl[:3])
+        Pd = pts[:, :3].astype(np.float64)
+        # the fitted normal leaves no more scatter than numpy's (the smallest eigenvalue, to rounding of the scatter matrix)
+        C = (Pd - Pd.mean(0)).T @ (Pd - Pd.mean(0))
+        lam_got, lam_np = pl[:3] @ C @ pl[:3], n @ C @ n
+        assert lam_got <= lam_np + 1e-12 * np.trace(C), (name, lam_got, lam_np)
+        if name != "nearly isotropic":
+            assert np.allclose(pl[:3], sgn * n, atol=2e-6), (name, pl[:3], n)
+    # degenerate: a line, and one point many times -- finite unit normal, zero determinant, probability 0
+    for P in degenerate.values():
+        pts = np.concatenate([P.astype(np.float32), np.ones((P.shape[0], 1), np.float32)], axis=1)
+        pt_ptr = np.array([0, pts.shape[0]], np.uint32)
+        pl, prob, err = O.mv_fit_segment(pts, pt_ptr, O.mv_vertex_moments(pts, pt_ptr), [0])
+        assert np.isfinite(pl).all() and abs(np.linalg.norm(pl[:3]) - 1.0) < 1e-12
+        assert abs(pl[4]) < 1e-9 and prob >= 0.0
+
+
 def test_pmerge_reference_properties():
     # TestGraphUtils.cpp:55-71
     rng = np.random.default_rng(2)
@@ -184,6 +233,29 @@ def test_gpu_vertex_moments_and_fit_bit_exact(gpu_mv, mv_small):
     for ms in sets:
         pl, prob, err = gpu_mv.fit_segment(ms)
         opl, oprob, oerr = O.mv_fit_segment(mv.points, mv.pt_ptr, vm, ms)
+        assert np.array_equal(pl.view(np.uint64), opl.view(np.uint64)), (ms, pl, opl)
+        assert np.float64(prob).view(np.uint64) == np.float64(oprob).view(np.uint64)
+        assert np.float64(err).view(np.uint64) == np.float64(oerr).view(np.uint64)
+
+
+@pytest.mark.gpu
+def test_gpu_plane_fit_hard_clouds_bit_exact(gpu_mv):
+    """The clouds of test_plane_fit_hard_clouds, one vertex each: the device's fit against the oracle's, bit for bit
+    (sweeps that stop early, rotations left out, the short form of a small angle, zero scatter)."""
+    clouds, degenerate = _hard_clouds()
+    Ps = list(clouds.values()) + list(degenerate.values())
+    pts = np.concatenate([np.concatenate([P.astype(np.float32), np.ones((P.shape[0], 1), np.float32)], axis=1) for P in Ps])
+    pt_ptr = np.concatenate([[0], np.cumsum([P.shape[0] for P in Ps])]).astype(np.uint32)
+    V = len(Ps)
+    rows = [[w for w in (v - 1, v + 1) if 0 <= w < V] for v in range(V)]            # a path graph
+    row_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.uint32)
+    col = np.concatenate(rows).astype(np.uint32)
+    gpu_mv.set_graph(pt_ptr, pts, row_ptr, col, np.full(col.size, 0.5))
+    vm = O.mv_vertex_moments(pts, pt_ptr)
+    assert np.array_equal(gpu_mv.vertex_moments().view(np.uint64), vm.view(np.uint64))
+    for ms in [[v] for v in range(V)] + [[0, 1], [2, 4, 5], list(range(V))]:
+        pl, prob, err = gpu_mv.fit_segment(ms)
+        opl, oprob, oerr = O.mv_fit_segment(pts, pt_ptr, vm, ms)
         assert np.array_equal(pl.view(np.uint64), opl.view(np.uint64)), (ms, pl, opl)
         assert np.float64(prob).view(np.uint64) == np.float64(oprob).view(np.uint64)
         assert np.float64(err).view(np.uint64) == np.float64(oerr).view(np.uint64)
