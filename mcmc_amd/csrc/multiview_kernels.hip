@@ -908,9 +908,10 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
             __syncthreads();
             // ---- phase 4: segment probabilities (MultiviewSegment.cpp:71-96), one wave each ----
             if (em != 1 && em != 3 && wave < 4 && !sh->have[wave]) {
-                // four rows per trip, fetched whether or not they are members (in the split iteration the table is
-                // behind L2 and a fetch per member would be one round trip after the other); only members are
-                // added, in vertex order
+                // four rows per trip: the membership tests first (LDS only), then the members' fetches together (in the
+                // split iteration the table is behind L2 -- 68 KB per chain, 70 MB for 1024 chains -- and a lane that
+                // is no member fetches nothing, so only the lines that hold a member's residual move); only members
+                // are added, in vertex order
                 double part = 0.0;
                 for (int v0 = lane; v0 < V; v0 += 4 * kWave) {
                     double tv[4]; bool in[4];
@@ -918,7 +919,11 @@ void mv_chain_run_kernel(MvGraph g, MvChainArgs a, MvExchange x)
                     for (int u = 0; u < 4; ++u) {
                         const int v = v0 + u * kWave;
                         in[u] = v < V && member(wave, v);
-                        tv[u] = L.errv[(size_t)wave * V + (v < V ? v : V - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        tv[u] = 0.0;
+                        if (in[u]) tv[u] = L.errv[(size_t)wave * V + (v0 + u * kWave)];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) if (in[u]) part += tv[u];
