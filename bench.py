@@ -407,9 +407,11 @@ def multiview_line(host, device, n_chains, steps):
     # the first half of the iteration (component growth + plane fits) has no byte stream and no matrix work: what is
     # known about its bound comes from recorded experiments, not from a live counter
     l1_kernel = {"kind": "recorded, not live: profiles/r03_multiview_kernel_stats.csv, r03_multiview_pmc.txt, r03_mfma_f64_abs_sum.txt, r03_l1_timeline.txt",
-                 "kernel_us_at_1024_chains_one_group": 50.7, "matrix_instructions_per_launch": 874029,
-                 "matrix_pipe_us_at_64_cycles": 21.6, "frac_of_f64_matrix_peak": 0.43,
-                 "ceiling_frac_with_abs_sums_on_the_same_pipe": 0.73, "frac_of_that_ceiling": 0.59,
+                 "kernel_us_at_1024_chains_one_group": 50.1, "matrix_instructions_per_launch": 874029,
+                 "matrix_pipe_us_at_64_cycles": 21.6, "frac_of_f64_matrix_peak": 0.45,
+                 "at_more_chains": [{"chains": 2048, "kernel_us": 89.4, "frac_of_f64_matrix_peak": 0.51},
+                                    {"chains": 4096, "kernel_us": 169.4, "matrix_instructions_per_launch": 3536840, "frac_of_f64_matrix_peak": 0.54}],
+                 "ceiling_frac_with_abs_sums_on_the_same_pipe": 0.73, "frac_of_that_ceiling": 0.62,
                  "note": "the four v_add_f64 |d| per matrix instruction share the f64 pipe with it: a SIMD saturates at 85-88 cycles "
                          "per product + additions (64 for the product alone); the rest is two round trips per item before its first "
                          "product and the spread of the SIMDs' totals (DESIGN.md section 5, K4)"}
