@@ -1031,16 +1031,28 @@ __global__ __launch_bounds__(kErrVertsPerGroup * kWave) void mv_err_pairs_kernel
         ppi = 16u * mv_err_groups_per_item(pcnt);                         // pairs per item of this vertex
         // lane l looks at chains c0 + 16 l .. + 15: all sixteen codes are fetched before any is used
         uint8_t* row = x.need + (size_t)v * n_chains;
+        if ((n_chains & 15) == 0 && (reinterpret_cast<uintptr_t>(x.need) & 15u) == 0) {
+            // the lane's sixteen codes are one aligned 16-byte word (rows and chain blocks start at multiples of 16)
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            uint4* qp = reinterpret_cast<uint4*>(row + c0 + 16 * lane);
+            if (c0 + 16 * lane < c1) q = *qp;
+            const uint32_t qq[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int cc = c0 + 16 * lane + k;
-            code[k] = cc < c1 ? (uint32_t)row[cc] : 0u;
+            for (int k = 0; k < 16; ++k) code[k] = (qq[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            mine = (uint32_t)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));      // codes are four bits wide
+            // every code is read exactly once, here: cleared for the next iteration
+            if (q.x | q.y | q.z | q.w) *qp = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int cc = c0 + 16 * lane + k;
+                code[k] = cc < c1 ? (uint32_t)row[cc] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mine += (uint32_t)__popc(code[k]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (code[k]) row[c0 + 16 * lane + k] = 0;
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mine += (uint32_t)__popc(code[k]);
-        // every code is read exactly once, here: cleared for the next iteration
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (code[k]) row[c0 + 16 * lane + k] = 0;
         // exclusive prefix over the lanes
         uint32_t incl = mine;
 #pragma unroll
