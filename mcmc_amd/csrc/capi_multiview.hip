@@ -506,8 +506,8 @@ int mcmc_mv_chains_run(mcmc_mv* c, uint64_t steps)
     }
     // A run leaves the growth of the step after its last one behind (it runs beside the last step's kernels); the next
     // run of the same chains starts from it.  Any other kind of run, new chains or an option set in between discard it.
-    const bool have_first = ahead && c->ahead_ready_step == (long long)c->step;
-    c->ahead_ready_step = -1;
+    const bool have_first = ahead && steps && c->ahead_ready_step == (long long)c->step;
+    if (steps) c->ahead_ready_step = -1;                         // a run of no steps launches nothing and leaves it
     if (split && c->ex_groups != G) {
         { uint8_t* p8 = static_cast<uint8_t*>(c->ex_sh); mvfree(p8); c->ex_sh = nullptr; }
         mvfree(c->ex_inE); mvfree(c->ex_need); mvfree(c->ex_err); mvfree(c->ex_plist); mvfree(c->ex_queue); mvfree(c->ex_counters);

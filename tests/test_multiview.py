@@ -522,8 +522,8 @@ def test_gpu_growth_a_step_ahead_changes_nothing(gpu_mv, split_prob, max_new):
     gpu_mv.set_option("growth_ahead_waves", 0)
     gpu_mv.chains_init(n, seed=6, chain_offset=2, max_new_segments=max_new, split_prob=split_prob)
     gpu_mv.chains_run(2)
-    gpu_mv.chains_run(0)
-    gpu_mv.chains_run(1)                                         # starts from the growth the run before left
+    gpu_mv.chains_run(0)                                         # launches nothing
+    gpu_mv.chains_run(1)                                         # starts from the growth the run of two steps left
     gpu_mv.set_option("growth_ahead", 0)
     gpu_mv.chains_run(2)
     gpu_mv.set_option("growth_ahead", 1)
